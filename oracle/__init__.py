@@ -1,0 +1,2 @@
+"""CPU oracle package -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see oracle.py)."""
+from .oracle import OracleConfig, OracleEnv, OraclePmi, build, lib, philox4x32_10  # noqa: F401

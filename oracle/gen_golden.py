@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference here.
+
+TEST INFRASTRUCTURE.  Runs only in the build container, where the reference is
+mounted read-only at /root/reference; it imports src/environment.py (and what
+that imports) and records inputs/outputs of Environment.reset/step as fp64 /
+int arrays.  Nothing of the reference's source travels: the fixtures are data.
+
+    PYTHONDONTWRITEBYTECODE=1 python3 oracle/gen_golden.py
+
+Scenarios:
+  g1  N5  M3   coop 0            1 seed  x 200 steps   (BASELINE configs[0])
+  g2  N20 M10  coop 0   (MAAC)   4 seeds x 30 steps
+  g3  N20 M10  coop .3  (MAAC-G) 4 seeds x 30 steps
+  g4  N20 M10  coop .3  PMI H128 4 seeds x 30 steps   (MAAC-R)
+  g5a N50 M25  coop 0            3 seeds x 12 steps
+  g5b N50 M25  coop .3  PMI      3 seeds x 12 steps
+  g6  reset-only layouts N in {5,10,20,50}
+  g7  hand-placed edge cases (walls, wraps, inclusive/strict thresholds, ...)
+"""
+import contextlib
+import io
+import json
+import math
+import os
+import random
+import sys
+
+import numpy as np
+
+REF = "/root/reference/src"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+import torch  # noqa: E402
+from environment import Environment  # noqa: E402  (reference)
+from models.PMINet import PMINetwork  # noqa: E402  (reference)
+
+torch.set_num_threads(1)
+
+
+def make_cfg(n_uav, m_targets, coop, x_max=2000, y_max=2000, na=12):
+    # identical environment/uav/target blocks of configs/*.yaml
+    return {
+        "environment": {"n_uav": n_uav, "m_targets": m_targets, "x_max": x_max, "y_max": y_max, "na": na},
+        "uav": {"dt": 1, "v_max": 20, "h_max": 6, "dc": 500, "dp": 200, "alpha": 0.6, "beta": 0.2, "gamma": 0.2},
+        "target": {"v_max": 5, "h_max": 6},
+        "cooperative": coop,
+    }
+
+
+def snap(env):
+    u, t = env.uav_list, env.target_list
+    return dict(ux=[a.x for a in u], uy=[a.y for a in u], uh=[a.h for a in u], ua=[a.a for a in u],
+                tx=[a.x for a in t], ty=[a.y for a in t], th=[a.h for a in t])
+
+
+def make_pmi(hidden=128, seed=42):
+    torch.manual_seed(seed)
+    pmi = PMINetwork(hidden_dim=hidden)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for bn in (pmi.bn_comm, pmi.bn_obs, pmi.bn_boundary_state, pmi.bn1):
+            bn.running_mean.copy_(torch.randn(hidden, generator=g) * 0.3)
+            bn.running_var.copy_(torch.rand(hidden, generator=g) * 1.5 + 0.5)
+            bn.weight.copy_(torch.rand(hidden, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(hidden, generator=g) * 0.2)
+    pmi.eval()
+    return pmi
+
+
+def run_episode(cfg, pmi, steps, seed=None, init=None, actions=None):
+    """Returns dict of stacked arrays: states [T+1,...], actions [T,N], outputs [T,...]."""
+    e = cfg["environment"]
+    env = Environment(n_uav=e["n_uav"], m_targets=e["m_targets"], x_max=e["x_max"], y_max=e["y_max"], na=e["na"])
+    if seed is not None:
+        random.seed(seed)
+    env.reset(config=cfg)
+    if init is not None:
+        for i, (x, y, h, a) in enumerate(init["uav"]):
+            u = env.uav_list[i]
+            u.x, u.y, u.h, u.a = float(x), float(y), float(h), int(a)
+        for k, (x, y, h) in enumerate(init["target"]):
+            t = env.target_list[k]
+            t.x, t.y, t.h = float(x), float(y), float(h)
+    with contextlib.redirect_stdout(io.StringIO()):
+        obs0 = np.array(env.get_states(), dtype=np.float64)
+    states = [snap(env)]
+    acts, obs, rew, terms, raw, cov = [], [], [], [], [], []
+    sink = io.StringIO()
+    for t in range(steps):
+        if actions is not None:
+            a = list(actions[t])
+        else:
+            a = [random.randint(0, e["na"] - 1) for _ in range(e["n_uav"])]
+        with contextlib.redirect_stdout(sink):
+            nxt, r, c = env.step(cfg, pmi, a)
+        acts.append(a)
+        obs.append(np.array(nxt, dtype=np.float64))
+        rew.append(np.array(r["rewards"], dtype=np.float64))
+        terms.append(np.array([r["target_tracking_reward"], r["boundary_punishment"],
+                               r["duplicate_tracking_punishment"]], dtype=np.float64))
+        raw.append(np.array([u.raw_reward for u in env.uav_list], dtype=np.float64))
+        cov.append(c)
+        states.append(snap(env))
+    out = {k: np.array([s[k] for s in states], dtype=(np.int64 if k == "ua" else np.float64))
+           for k in states[0]}
+    out.update(actions=np.array(acts, dtype=np.int64).reshape(steps, e["n_uav"]),
+               obs=np.array(obs), reward=np.array(rew), terms=np.array(terms), raw=np.array(raw),
+               covered=np.array(cov, dtype=np.int64), obs0=obs0,
+               overstep_prints=np.int64(sink.getvalue().count("overstep")))
+    return out
+
+
+def stack_eps(eps):
+    return {k: np.stack([e[k] for e in eps]) for k in eps[0]}
+
+
+def save(name, arrays, meta):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, meta=np.array(json.dumps(meta)), **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def scenario(name, n, m, coop, pmi, seeds, steps):
+    cfg = make_cfg(n, m, coop)
+    eps = [run_episode(cfg, pmi, steps, seed=s) for s in seeds]
+    save(name, stack_eps(eps), dict(n_uav=n, m_targets=m, cooperative=coop, pmi=pmi is not None,
+                                    seeds=list(seeds), steps=steps, cfg=cfg))
+
+
+def gen_reset():
+    arrays, meta = {}, {}
+    for n, m in ((5, 3), (10, 10), (20, 10), (50, 25)):
+        cfg = make_cfg(n, m, 0)
+        ep = run_episode(cfg, None, 0, seed=42)
+        for k in ("ux", "uy", "uh", "ua", "tx", "ty", "th", "obs0"):
+            arrays[f"n{n}_{k}"] = ep[k][0] if k != "obs0" else ep[k]
+        meta[f"n{n}"] = dict(n_uav=n, m_targets=m)
+    save("g6_reset", arrays, meta)
+
+
+def gen_edges(pmi):
+    """Hand-placed single/double-step cases; each gets its own key prefix."""
+    P = math.pi
+    cases = []
+
+    def add(name, uav, target, actions, coop=0.0, use_pmi=False):
+        cases.append(dict(name=name, uav=uav, target=target, actions=actions, coop=coop, use_pmi=use_pmi))
+
+    far_t = [(1000.0, 1900.0, 0.3)]
+    # targets crossing each wall, a corner (y has priority), h>0 vs h<=0 at x walls
+    add("target_walls",
+        uav=[(300.0, 300.0, 0.0, 3)],
+        target=[(1998.0, 1000.0, 0.1), (1998.0, 1000.0, -0.1), (2.0, 1000.0, P - 0.1), (2.0, 1000.0, -P + 0.1),
+                (1000.0, 1998.0, P / 2), (1000.0, 2.0, -P / 2), (1998.0, 1998.0, P / 4), (1998.0, 2.0, -P / 4),
+                (2.0, 2.0, -3 * P / 4), (1999.0, 500.0, 0.0)],
+        actions=[[5], [6], [6]])
+    # heading wrap both ways
+    add("heading_wrap",
+        uav=[(1000.0, 1000.0, P - 0.05, 0), (1200.0, 1000.0, -P + 0.05, 0), (800.0, 900.0, P - 0.3, 4)],
+        target=far_t, actions=[[11, 0, 11], [11, 0, 11], [0, 11, 11]])
+    # outside the box (-0.5 -> bp -1) and d_b exactly dp (not < dp -> 0)
+    add("boundary",
+        uav=[(-30.0, 1000.0, 0.0, 5), (180.0, 1000.0, 0.0, 5), (1000.0, 1995.0, P / 2, 5), (1000.0, 150.0, 0.0, 5)],
+        target=far_t, actions=[[5, 5, 6, 6]])
+    # inclusive thresholds: target exactly dp (obs/track yes, coverage no); peer exactly dc; 2dp; dp
+    add("thresholds",
+        uav=[(480.0, 1000.0, 0.0, 2), (1000.0, 1000.0, 0.0, 7), (880.0, 400.0, 0.0, 1), (480.0, 400.0, 0.0, 9),
+             (680.0, 1600.0, 0.0, 3), (480.0, 1600.0, 0.0, 3)],
+        target=[(695.0, 1000.0, 0.0), (200.0, 1000.0, 0.0)],
+        actions=[[5, 6, 5, 6, 5, 6]], coop=0.3)
+    add("thresholds_pmi",
+        uav=[(480.0, 1000.0, 0.0, 2), (1000.0, 1000.0, 0.0, 7), (880.0, 400.0, 0.0, 1), (480.0, 400.0, 0.0, 9),
+             (680.0, 1600.0, 0.0, 3), (480.0, 1600.0, 0.0, 3)],
+        target=[(695.0, 1000.0, 0.0), (200.0, 1000.0, 0.0)],
+        actions=[[5, 6, 5, 6, 5, 6]], coop=0.3, use_pmi=True)
+    # uav.py:165/179 weight min(d,1) < 1: UAV ends within 1 m of its normalised offsets
+    add("near_origin_weight",
+        uav=[(-19.7, 0.2, 0.0, 4), (100.0, 50.0, 1.0, 2), (-19.9, 0.6, 0.0, 8)],
+        target=[(50.0, 60.0, 0.5), (120.0, -10.0, 2.0)],
+        actions=[[5, 6, 7]], coop=0.3)
+    # nothing observed, no neighbours: MAAC-G gives 0 (uav.py:308-309), MAAC-R gives (1-a)*raw (uav.py:290)
+    add("isolated_mean",
+        uav=[(100.0, 100.0, 0.3, 0), (1900.0, 1900.0, -2.0, 11), (100.0, 1900.0, 1.0, 4)],
+        target=[(1000.0, 1000.0, 0.0)], actions=[[1, 2, 3]], coop=0.3)
+    add("isolated_pmi",
+        uav=[(100.0, 100.0, 0.3, 0), (1900.0, 1900.0, -2.0, 11), (100.0, 1900.0, 1.0, 4)],
+        target=[(1000.0, 1000.0, 0.0)], actions=[[1, 2, 3]], coop=0.3, use_pmi=True)
+    # all UAVs coincident: max duplicate punishment, j<i sees d=0, j>i sees d=20
+    add("coincident",
+        uav=[(1000.0, 1000.0, 0.7, 3)] * 5,
+        target=[(1010.0, 1010.0, 0.0), (1500.0, 1500.0, 1.0)],
+        actions=[[6, 6, 6, 6, 6], [0, 11, 5, 6, 3]], coop=0.3)
+    add("coincident_pmi",
+        uav=[(1000.0, 1000.0, 0.7, 3)] * 5,
+        target=[(1010.0, 1010.0, 0.0), (1500.0, 1500.0, 1.0)],
+        actions=[[6, 6, 6, 6, 6], [0, 11, 5, 6, 3]], coop=0.3, use_pmi=True)
+    # dense cluster, many targets in range: tracking sum, coverage, softmax over many neighbours
+    rng = np.random.RandomState(7)
+    n, m = 12, 8
+    add("dense_cluster_pmi",
+        uav=[(float(900 + rng.rand() * 250), float(900 + rng.rand() * 250), float(rng.uniform(-P, P)),
+              int(rng.randint(0, 12))) for _ in range(n)],
+        target=[(float(850 + rng.rand() * 350), float(850 + rng.rand() * 350), float(rng.uniform(-P, P)))
+                for _ in range(m)],
+        actions=[[int(a) for a in rng.randint(0, 12, size=n)] for _ in range(3)], coop=0.3, use_pmi=True)
+
+    arrays, meta = {}, {"cases": []}
+    for c in cases:
+        n, m = len(c["uav"]), len(c["target"])
+        cfg = make_cfg(n, m, c["coop"])
+        ep = run_episode(cfg, pmi if c["use_pmi"] else None, len(c["actions"]), seed=1,
+                         init=dict(uav=c["uav"], target=c["target"]), actions=c["actions"])
+        for k, v in ep.items():
+            arrays[f"{c['name']}__{k}"] = v
+        meta["cases"].append(dict(name=c["name"], n_uav=n, m_targets=m, cooperative=c["coop"],
+                                  pmi=c["use_pmi"], steps=len(c["actions"])))
+    save("g7_edges", arrays, meta)
+
+
+def main():
+    pmi = make_pmi(128, 42)
+    sd = {k: v.detach().numpy().astype(np.float32) for k, v in pmi.state_dict().items()
+          if "num_batches_tracked" not in k}
+    save("pmi_h128", sd, dict(hidden=128, bn_eps=1e-5, torch_seed=42))
+    scenario("g1_n5m3_raw", 5, 3, 0, None, [42], 200)
+    scenario("g2_n20m10_raw", 20, 10, 0, None, [42, 43, 44, 45], 30)
+    scenario("g3_n20m10_mean", 20, 10, 0.3, None, [42, 43, 44, 45], 30)
+    scenario("g4_n20m10_pmi", 20, 10, 0.3, pmi, [42, 43, 44, 45], 30)
+    scenario("g5a_n50m25_raw", 50, 25, 0, None, [42, 43, 44], 12)
+    scenario("g5b_n50m25_pmi", 50, 25, 0.3, pmi, [42, 43, 44], 12)
+    gen_reset()
+    gen_edges(pmi)
+
+
+if __name__ == "__main__":
+    main()

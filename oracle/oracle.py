@@ -1,0 +1,227 @@
+"""ctypes front-end of the CPU oracle (oracle/uav_oracle.c).
+
+TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg may import this module; the HIP path under
+marl-uavs-targets-tracking_amd/ never does.
+
+The oracle restates /root/reference/src/environment.py:120-164 (step) and the
+functions it calls in fp64; see uav_oracle.c for the per-function citations.
+Parity status: PINNED by tests/golden/ (tests/test_oracle_golden.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+
+class _Cfg(C.Structure):
+    _fields_ = [
+        ("n_envs", C.c_int32), ("n_uav", C.c_int32), ("m_targets", C.c_int32),
+        ("dim", C.c_int32), ("na", C.c_int32), ("nc", C.c_int32),
+        ("norm_n_uav", C.c_int32), ("norm_m_targets", C.c_int32),
+        ("x_max", C.c_double), ("y_max", C.c_double), ("z_max", C.c_double),
+        ("dt", C.c_double), ("u_v_max", C.c_double), ("u_h_max", C.c_double),
+        ("u_g_max", C.c_double), ("dc", C.c_double), ("dp", C.c_double),
+        ("t_v_max", C.c_double),
+        ("alpha", C.c_double), ("beta", C.c_double), ("gamma", C.c_double),
+        ("cooperative", C.c_double),
+    ]
+
+
+class _Pmi(C.Structure):
+    _fields_ = [("hidden", C.c_int32)] + [
+        (n, C.POINTER(C.c_double)) for n in (
+            "w_comm", "b_comm", "bn_comm", "w_obs", "b_obs", "bn_obs",
+            "w_bs", "b_bs", "bn_bs", "w_fc1", "b_fc1", "bn_fc1", "w_fc2", "b_fc2")
+    ] + [("bn_eps", C.c_double)]
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so with the committed Makefile (gcc, -fopenmp)."""
+    src = os.path.join(_HERE, "uav_oracle.c")
+    hdr = os.path.join(_HERE, "uav_oracle.h")
+    stale = (not os.path.exists(_LIB_PATH)
+             or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-B", "liboracle.so"], check=True,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_step.restype = C.c_int
+        _lib.orc_reset_obs.restype = C.c_int
+        _lib.orc_reset_philox.restype = C.c_int
+        _lib.orc_philox4x32_10.restype = None
+    return _lib
+
+
+@dataclass
+class OracleConfig:
+    """Reference constants (configs/*.yaml, identical in all four)."""
+    n_envs: int = 1
+    n_uav: int = 10
+    m_targets: int = 10
+    dim: int = 2
+    na: int = 12
+    nc: int = 1
+    x_max: float = 2000.0
+    y_max: float = 2000.0
+    z_max: float = 500.0
+    dt: float = 1.0
+    u_v_max: float = 20.0
+    u_h_max: float = math.pi / 6.0       # yaml h_max: 6 means pi/6 (environment.py:100)
+    u_g_max: float = math.pi / 12.0
+    dc: float = 500.0
+    dp: float = 200.0
+    t_v_max: float = 5.0
+    alpha: float = 0.6
+    beta: float = 0.2
+    gamma: float = 0.2
+    cooperative: float = 0.0
+    norm_n_uav: Optional[int] = None
+    norm_m_targets: Optional[int] = None
+
+    def c_struct(self) -> _Cfg:
+        return _Cfg(self.n_envs, self.n_uav, self.m_targets, self.dim, self.na, self.nc,
+                    self.n_uav if self.norm_n_uav is None else self.norm_n_uav,
+                    self.m_targets if self.norm_m_targets is None else self.norm_m_targets,
+                    self.x_max, self.y_max, self.z_max, self.dt, self.u_v_max, self.u_h_max,
+                    self.u_g_max, self.dc, self.dp, self.t_v_max,
+                    self.alpha, self.beta, self.gamma, self.cooperative)
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+@dataclass
+class OraclePmi:
+    """Unfolded PMINetwork parameters, built from a torch state_dict (PMINet.py:29-38)."""
+    hidden: int
+    arrays: Dict[str, np.ndarray] = field(default_factory=dict)
+    bn_eps: float = 1e-5
+
+    @classmethod
+    def from_state_dict(cls, sd) -> "OraclePmi":
+        def g(k):
+            v = sd[k]
+            v = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+            return np.ascontiguousarray(v, dtype=np.float64)
+
+        def bn(p):
+            return np.ascontiguousarray(np.stack([g(p + ".weight"), g(p + ".bias"),
+                                                  g(p + ".running_mean"), g(p + ".running_var")]))
+        H = g("fc_comm.weight").shape[0]
+        arrays = dict(
+            w_comm=g("fc_comm.weight"), b_comm=g("fc_comm.bias"), bn_comm=bn("bn_comm"),
+            w_obs=g("fc_obs.weight"), b_obs=g("fc_obs.bias"), bn_obs=bn("bn_obs"),
+            w_bs=g("fc_boundary_state.weight"), b_bs=g("fc_boundary_state.bias"),
+            bn_bs=bn("bn_boundary_state"),
+            w_fc1=g("fc1.weight"), b_fc1=g("fc1.bias"), bn_fc1=bn("bn1"),
+            w_fc2=g("fc2.weight"), b_fc2=g("fc2.bias"))
+        return cls(hidden=int(H), arrays=arrays)
+
+    def c_struct(self) -> _Pmi:
+        p = _Pmi()
+        p.hidden = self.hidden
+        for k, v in self.arrays.items():
+            setattr(p, k, _dp(v))
+        p.bn_eps = self.bn_eps
+        return p
+
+
+class OracleEnv:
+    """Batched fp64 environment state + step, mirroring Environment (environment.py:12)."""
+
+    def __init__(self, cfg: OracleConfig, n_threads: int = 1):
+        self.cfg = cfg
+        self.n_threads = n_threads
+        B, N, M = cfg.n_envs, cfg.n_uav, cfg.m_targets
+        self.ux = np.zeros(B * N); self.uy = np.zeros(B * N); self.uh = np.zeros(B * N)
+        self.uz = np.zeros(B * N) if cfg.dim == 3 else None
+        self.ua = np.zeros(B * N, dtype=np.int32)
+        self.tx = np.zeros(B * M); self.ty = np.zeros(B * M); self.th = np.zeros(B * M)
+        self.tz = np.zeros(B * M) if cfg.dim == 3 else None
+        self.pmi: Optional[OraclePmi] = None
+
+    # -- state injection (values are copied, widened to fp64) -----------------
+    def set_state(self, ux, uy, uh, ua, tx, ty, th, uz=None, tz=None):
+        for dst, src in ((self.ux, ux), (self.uy, uy), (self.uh, uh),
+                         (self.tx, tx), (self.ty, ty), (self.th, th)):
+            dst[:] = np.asarray(src, dtype=np.float64).reshape(-1)
+        self.ua[:] = np.asarray(ua, dtype=np.int32).reshape(-1)
+        if self.cfg.dim == 3:
+            self.uz[:] = np.asarray(uz, dtype=np.float64).reshape(-1)
+            self.tz[:] = np.asarray(tz, dtype=np.float64).reshape(-1)
+
+    def get_state(self):
+        B, N, M = self.cfg.n_envs, self.cfg.n_uav, self.cfg.m_targets
+        out = dict(ux=self.ux.reshape(B, N).copy(), uy=self.uy.reshape(B, N).copy(),
+                   uh=self.uh.reshape(B, N).copy(), ua=self.ua.reshape(B, N).copy(),
+                   tx=self.tx.reshape(B, M).copy(), ty=self.ty.reshape(B, M).copy(),
+                   th=self.th.reshape(B, M).copy())
+        if self.cfg.dim == 3:
+            out["uz"] = self.uz.reshape(B, N).copy()
+            out["tz"] = self.tz.reshape(B, M).copy()
+        return out
+
+    def reset_philox(self, seed: int, episode: int = 0, env_offset: int = 0):
+        c = self.cfg.c_struct()
+        rc = lib().orc_reset_philox(C.byref(c), C.c_uint64(seed), C.c_uint32(episode),
+                                    C.c_int64(env_offset),
+                                    _dp(self.ux), _dp(self.uy), _dp(self.uz), _dp(self.uh), _ip(self.ua),
+                                    _dp(self.tx), _dp(self.ty), _dp(self.tz), _dp(self.th))
+        assert rc == 0, rc
+        return self.reset_obs()
+
+    def reset_obs(self):
+        B, N = self.cfg.n_envs, self.cfg.n_uav
+        obs = np.empty((B, N, 12))
+        c = self.cfg.c_struct()
+        lib().orc_reset_obs(C.byref(c), _dp(self.ux), _dp(self.uy), _ip(self.ua), _dp(obs))
+        return obs
+
+    def step(self, actions):
+        """-> dict(obs[B,N,12], reward[B,N], terms[3,B,N], raw[B,N], covered[B], margin[B])."""
+        B, N = self.cfg.n_envs, self.cfg.n_uav
+        act = np.ascontiguousarray(np.asarray(actions, dtype=np.int32).reshape(B * N))
+        obs = np.empty((B, N, 12)); reward = np.empty((B, N)); terms = np.empty((3, B, N))
+        raw = np.empty((B, N)); covered = np.empty(B, dtype=np.int32); margin = np.empty(B)
+        c = self.cfg.c_struct()
+        pm = self.pmi.c_struct() if self.pmi is not None else None
+        rc = lib().orc_step(C.byref(c),
+                            _dp(self.ux), _dp(self.uy), _dp(self.uz), _dp(self.uh), _ip(self.ua),
+                            _dp(self.tx), _dp(self.ty), _dp(self.tz), _dp(self.th),
+                            _ip(act), C.byref(pm) if pm is not None else None,
+                            _dp(obs), _dp(reward), _dp(terms), _dp(raw), _ip(covered), _dp(margin),
+                            C.c_int(self.n_threads))
+        if rc != 0:
+            raise RuntimeError(f"orc_step failed: {rc}")
+        return dict(obs=obs, reward=reward, terms=terms, raw=raw, covered=covered, margin=margin)
+
+
+def philox4x32_10(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr); k = (C.c_uint32 * 2)(*key); o = (C.c_uint32 * 4)()
+    lib().orc_philox4x32_10(c, k, o)
+    return [int(v) for v in o]

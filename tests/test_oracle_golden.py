@@ -1,0 +1,136 @@
+"""Pins the CPU oracle (oracle/uav_oracle.c) to golden vectors produced by the
+unmodified reference (oracle/gen_golden.py).  fp64 vs fp64: tolerance 1e-12
+(1e-6 where the reference runs the PMI net in fp32 torch)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import OracleConfig, OracleEnv, OraclePmi
+
+TOL = 1e-12
+TOL_PMI = 2e-6   # reference PMINetwork runs in fp32 torch (PMINet.py:41-62); oracle folds nothing, fp64
+
+
+def ang_diff(a, b):
+    d = (np.asarray(a) - np.asarray(b) + np.pi) % (2 * np.pi) - np.pi
+    return np.abs(d)
+
+
+def check_episode(z, pre, e, meta_case, pmi_sd, steps):
+    """Teacher-forced: inject the reference state before every step, run one oracle step."""
+    n, m = meta_case["n_uav"], meta_case["m_targets"]
+    cfg = OracleConfig(n_envs=1, n_uav=n, m_targets=m, cooperative=meta_case["cooperative"])
+    env = OracleEnv(cfg)
+    if meta_case["pmi"]:
+        env.pmi = OraclePmi.from_state_dict(pmi_sd)
+    tol_r = TOL_PMI if meta_case["pmi"] else TOL
+
+    def g(k):
+        a = z[pre + k]
+        return a if e is None else a[e]
+
+    for t in range(steps):
+        env.set_state(g("ux")[t], g("uy")[t], g("uh")[t], g("ua")[t], g("tx")[t], g("ty")[t], g("th")[t])
+        out = env.step(g("actions")[t])
+        st = env.get_state()
+        for k in ("ux", "uy", "tx", "ty"):
+            np.testing.assert_allclose(st[k][0], g(k)[t + 1], rtol=0, atol=TOL * 2000, err_msg=f"{pre}{k} t={t}")
+        assert ang_diff(st["uh"][0], g("uh")[t + 1]).max() < 1e-12
+        assert ang_diff(st["th"][0], g("th")[t + 1]).max() < 1e-12
+        np.testing.assert_array_equal(st["ua"][0], g("ua")[t + 1])
+        np.testing.assert_allclose(out["obs"][0], g("obs")[t], rtol=0, atol=1e-11, err_msg=f"{pre}obs t={t}")
+        np.testing.assert_allclose(out["terms"][:, 0], g("terms")[t], rtol=0, atol=TOL, err_msg=f"{pre}terms t={t}")
+        np.testing.assert_allclose(out["raw"][0], g("raw")[t], rtol=0, atol=TOL, err_msg=f"{pre}raw t={t}")
+        np.testing.assert_allclose(out["reward"][0], g("reward")[t], rtol=0, atol=tol_r, err_msg=f"{pre}reward t={t}")
+        assert int(out["covered"][0]) == int(g("covered")[t]), f"{pre}covered t={t}"
+
+
+@pytest.mark.parametrize("name", ["g1_n5m3_raw", "g2_n20m10_raw", "g3_n20m10_mean", "g4_n20m10_pmi",
+                                  "g5a_n50m25_raw", "g5b_n50m25_pmi"])
+def test_teacher_forced(name, pmi_state_dict):
+    z, meta = load_golden(name)
+    assert int(z["overstep_prints"].sum()) == 0
+    for e in range(len(meta["seeds"])):
+        check_episode(z, "", e, meta, pmi_state_dict, meta["steps"])
+
+
+def test_free_running_rollout():
+    """fp64 oracle free-runs the whole 200-step episode of g1 from the initial state."""
+    z, meta = load_golden("g1_n5m3_raw")
+    cfg = OracleConfig(n_envs=1, n_uav=5, m_targets=3)
+    env = OracleEnv(cfg)
+    env.set_state(*(z[k][0, 0] for k in ("ux", "uy", "uh", "ua", "tx", "ty", "th")))
+    for t in range(meta["steps"]):
+        out = env.step(z["actions"][0, t])
+        np.testing.assert_allclose(out["obs"][0], z["obs"][0, t], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(out["reward"][0], z["reward"][0, t], rtol=0, atol=1e-10)
+        assert int(out["covered"][0]) == int(z["covered"][0, t])
+    st = env.get_state()
+    np.testing.assert_allclose(st["ux"][0], z["ux"][0, -1], rtol=0, atol=1e-9)
+
+
+def test_edge_cases(pmi_state_dict):
+    z, meta = load_golden("g7_edges")
+    for case in meta["cases"]:
+        check_episode(z, case["name"] + "__", None, case, pmi_state_dict, case["steps"])
+
+
+def test_edge_case_semantics():
+    """The goldens really exercise the quirks they are named for."""
+    z, _ = load_golden("g7_edges")
+    # MAAC-G with no neighbour: reward is exactly 0 (uav.py:308-309); MAAC-R keeps (1-a)*raw (uav.py:290)
+    assert np.all(z["isolated_mean__reward"] == 0.0)
+    np.testing.assert_allclose(z["isolated_pmi__reward"], 0.7 * z["isolated_pmi__raw"], atol=1e-15)
+    # target exactly dp away: tracked (inclusive) but not covered (strict)
+    assert z["thresholds__terms"][0, 0, 0] == 0.25 and int(z["thresholds__covered"][0]) == 0
+    # outside the box -> normalised boundary punishment -1; d_b == dp -> 0
+    assert z["boundary__terms"][0, 1, 0] == -1.0 and z["boundary__terms"][0, 1, 1] == 0.0
+    # corner: y has priority, heading only negated
+    np.testing.assert_allclose(z["target_walls__th"][1, 6], -np.pi / 4, atol=1e-15)
+    # weight < 1 changes the mean: peers are <= 100 m away, so the unweighted |dx|/dc mean is <= 0.2
+    assert np.abs(z["near_origin_weight__obs"][0, 0, :2]).max() > 0.5
+
+
+def test_reset_layout_and_first_obs():
+    z, meta = load_golden("g6_reset")
+    for key, mc in meta.items():
+        n, m = mc["n_uav"], mc["m_targets"]
+        ux, uy, ua = z[f"{key}_ux"], z[f"{key}_uy"], z[f"{key}_ua"]
+        np.testing.assert_allclose(ux, np.arange(1, n + 1) * 2000.0 / (n + 1), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(uy, 1000.0)
+        cfg = OracleConfig(n_envs=1, n_uav=n, m_targets=m)
+        env = OracleEnv(cfg)
+        env.set_state(ux, uy, z[f"{key}_uh"], ua, z[f"{key}_tx"], z[f"{key}_ty"], z[f"{key}_th"])
+        np.testing.assert_allclose(env.reset_obs()[0], z[f"{key}_obs0"], rtol=0, atol=1e-15)
+
+
+def test_philox_known_answer():
+    """Random123 kat_vectors: philox4x32-10."""
+    from oracle import philox4x32_10
+    assert philox4x32_10([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_philox_reset_ranges_and_shard_independence():
+    cfg = OracleConfig(n_envs=8, n_uav=20, m_targets=10)
+    full = OracleEnv(cfg); full.reset_philox(seed=42)
+    s = full.get_state()
+    assert np.all((s["uh"] >= -np.pi - 1e-6) & (s["uh"] < np.pi + 1e-6))
+    assert s["ua"].min() >= 0 and s["ua"].max() <= 11
+    assert np.all((s["tx"] >= 0) & (s["tx"] < 2000)) and np.all((s["ty"] >= 0) & (s["ty"] < 2000))
+    half = OracleEnv(OracleConfig(n_envs=4, n_uav=20, m_targets=10)); half.reset_philox(seed=42, env_offset=4)
+    h = half.get_state()
+    for k in s:
+        np.testing.assert_array_equal(s[k][4:], h[k])
+
+
+def test_threads_agree():
+    cfg = OracleConfig(n_envs=64, n_uav=20, m_targets=10, cooperative=0.3)
+    a, b = OracleEnv(cfg, n_threads=1), OracleEnv(cfg, n_threads=4)
+    a.reset_philox(3); b.reset_philox(3)
+    act = np.random.RandomState(0).randint(0, 12, size=(64, 20))
+    oa, ob = a.step(act), b.step(act)
+    for k in oa:
+        np.testing.assert_array_equal(oa[k], ob[k])
