@@ -1,0 +1,157 @@
+/*
+ * uavtrack.h -- C ABI of libuavtrack.so, the MI355X (gfx950) batched
+ * multi-UAV target-tracking environment.
+ *
+ * The reference (tjuDavidWang/MARL-UAVs-Targets-Tracking) has no FFI: its hot
+ * path is the duck-typed Python class `Environment` (src/environment.py:12).
+ * Each entry point below names the reference interface it replaces; the Python
+ * binding a maintainer adds on the reference side is in INTEGRATION.md and is
+ * what marl-uavs-targets-tracking_amd/uavtrack/_lib.py implements (ctypes).
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on failure; the message is
+ *    in uavtrack_last_error() (thread-local).  No exceptions cross the ABI.
+ *  - all array arguments are DEVICE pointers (HIP), caller-owned, contiguous,
+ *    fp32 / int32 / uint8 as declared.  The library keeps no reference to them
+ *    after the stream work it enqueued has run.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *    Every call is asynchronous on that stream; nothing synchronises the host.
+ *  - a handle is owned by one host thread at a time (like the reference's
+ *    single-threaded Environment); one handle per GPU, one process per GPU.
+ *  - batch layout is struct-of-arrays: UAV arrays are [n_envs][n_uav], target
+ *    arrays [n_envs][m_targets], row-major, environment-major.
+ *  - there is no CPU fallback: on a machine without a gfx950 device
+ *    uavtrack_create fails.
+ */
+#ifndef UAVTRACK_H
+#define UAVTRACK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UAVTRACK_ABI_VERSION 1
+#define UAVTRACK_OBS_DIM 12      /* environment.py:28  state_dim = (4+1) + 4 + (2+1) */
+#define UAVTRACK_MAX_CLIMB 8
+
+/* Which cooperative reward runs in Environment.calculate_rewards
+ * (environment.py:222-226 -> uav.py:312-322). */
+enum uavtrack_reward_mode {
+    UAVTRACK_REWARD_RAW  = 0,   /* MAAC:   cooperative == 0, reward = raw      (uav.py:270,300) */
+    UAVTRACK_REWARD_MEAN = 1,   /* MAAC-G: pmi is None, neighbour mean         (uav.py:293-310) */
+    UAVTRACK_REWARD_PMI  = 2    /* MAAC-R: PMI-softmax weighted neighbours     (uav.py:262-291) */
+};
+
+/* Everything Environment.__init__ (environment.py:13-43), Environment.reset
+ * (environment.py:87-107) and the per-step `config` dict reads
+ * (environment.py:207-224) -- captured once, as a POD. */
+typedef struct uavtrack_config {
+    uint32_t struct_size;       /* = sizeof(uavtrack_config), ABI check */
+    int32_t  n_envs;            /* B: independent Environment instances on this GPU */
+    int32_t  n_uav;             /* environment.n_uav      (environment.py:32) */
+    int32_t  m_targets;         /* environment.m_targets  (environment.py:33) */
+    int32_t  dim;               /* 2 (reference) or 3 (our own spec) */
+    int32_t  na;                /* environment.na, turn-rate actions (uav.py:73-81) */
+    int32_t  nc;                /* climb-angle actions, 1 in 2-D; action = a_turn + na * a_climb */
+    int32_t  norm_n_uav;        /* config['environment']['n_uav'] of the clip   (environment.py:210) */
+    int32_t  norm_m_targets;    /* config['environment']['m_targets'] of the clip (environment.py:208) */
+    int32_t  reward_mode;       /* enum uavtrack_reward_mode */
+    int32_t  horizon;           /* done[b] = step_count[b] >= horizon (train.py:160 num_steps); 0 = never */
+    int32_t  device_id;         /* HIP device ordinal */
+    int64_t  env_offset;        /* global id of env 0 of this shard (keys the reset RNG; multi-GPU) */
+    double   x_max, y_max, z_max;
+    double   dt;                /* uav.dt */
+    double   u_v_max;           /* uav.v_max */
+    double   u_h_max;           /* radians: pi / yaml uav.h_max (environment.py:100) */
+    double   u_g_max;           /* radians: max climb angle (3-D only) */
+    double   dc, dp;            /* uav.dc, uav.dp */
+    double   t_v_max;           /* target.v_max */
+    double   alpha, beta, gamma;/* uav.alpha/beta/gamma (environment.py:219-220) */
+    double   cooperative;       /* config['cooperative'] (environment.py:224) */
+} uavtrack_config;
+
+typedef struct uavtrack_env uavtrack_env;   /* opaque handle */
+
+/* ABI version of the loaded library. */
+int uavtrack_version(void);
+
+/* Message of the last failure on this thread ("" if none). */
+const char *uavtrack_last_error(void);
+
+/* Replaces Environment.__init__ (environment.py:13-43).  Allocates the
+ * internal SoA state on cfg->device_id.  Fails if no gfx950 device. */
+int uavtrack_create(const uavtrack_config *cfg, uavtrack_env **out);
+
+/* Frees the handle and its device state. */
+int uavtrack_destroy(uavtrack_env *env);
+
+/* Replaces Environment.reset (environment.py:87-107): UAV i (1-based) at
+ * x = i*x_max/(n_uav+1), y = y_max/2 [, z = z_max/2], heading ~ U(-pi,pi),
+ * previous action ~ U{0..na*nc-1}; targets uniform in the box, heading
+ * ~ U(-pi,pi).  The reference draws from Python's MT19937; here the stream is
+ * Philox4x32-10 keyed by (seed, env_offset + b, episode, agent), so a shard
+ * reproduces the same envs as the unsharded batch.  step_count <- 0.
+ * obs (nullable) [B][N][12] receives get_states() of the fresh state:
+ * [-1]*9 + [x/dc, y/dc, a/Na] (uav.py:174,186). */
+int uavtrack_reset(uavtrack_env *env, uint64_t seed, uint32_t episode,
+                   float *obs, void *stream);
+
+/* State injection / extraction (no reference equivalent: the reference pokes
+ * uav.x / target.x attributes directly; used for parity tests and as the env
+ * checkpoint).  uz/tz are ignored (may be NULL) when dim == 2.  step_count
+ * (nullable) is int32[B]. */
+int uavtrack_set_state(uavtrack_env *env,
+                       const float *ux, const float *uy, const float *uz, const float *uh,
+                       const int32_t *ua,
+                       const float *tx, const float *ty, const float *tz, const float *th,
+                       const int32_t *step_count, void *stream);
+int uavtrack_get_state(uavtrack_env *env,
+                       float *ux, float *uy, float *uz, float *uh, int32_t *ua,
+                       float *tx, float *ty, float *tz, float *th,
+                       int32_t *step_count, void *stream);
+
+/* Replaces the `pmi` argument of Environment.step (environment.py:120;
+ * PMINetwork.inference PMINet.py:64-72, eval mode).  `folded` is a HOST
+ * pointer to the BatchNorm-folded fp32 blob, layout (H = hidden):
+ *   Wc[5][H] bc[H]  Wo[4][H] bo[H]  Wb[3][H] bb[H]  W1[3H][H] b1[H]  w2[H] b2[1]
+ * (input-major so consecutive lanes read consecutive outputs).  n_floats must
+ * equal 12H + 3H + 3H*H + H + H + 1.  folded == NULL disables PMI. */
+int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_floats,
+                             int32_t hidden, void *stream);
+
+/* Replaces Environment.step (environment.py:120-164) for the whole batch.
+ *   actions [B][N] int32 in [0, na*nc)      (train.py:173-176 action_list)
+ *   obs     [B][N][12]  next_states          (environment.py:144)
+ *   reward  [B][N]      reward['rewards']    (environment.py:158)
+ *   terms   [3][B][N]   target_tracking_reward, boundary_punishment,
+ *                       duplicate_tracking_punishment (environment.py:159-161); nullable
+ *   covered [B] int32   covered_targets      (environment.py:146); nullable
+ *   done    [B] uint8   step_count >= horizon; nullable */
+int uavtrack_step(uavtrack_env *env, const int32_t *actions,
+                  float *obs, float *reward, float *terms,
+                  int32_t *covered, uint8_t *done, void *stream);
+
+/* T consecutive steps in ONE launch with the state resident on chip
+ * (replaces the `for i in range(num_steps)` loop of train.py:160-185 for
+ * open-loop / pre-sampled actions).  Bitwise identical to T uavtrack_step
+ * calls.  Outputs gain a leading [T] axis: actions [T][B][N], obs
+ * [T][B][N][12], reward [T][B][N], terms [T][3][B][N], covered [T][B],
+ * done [T][B].  ep_sums (nullable) [B][5] receives the episode accumulators of
+ * train.py:181-192 over the T steps: sum_t mean_i reward, sum_t mean_i of the
+ * three terms, sum_t covered. obs/terms/covered/done/ep_sums are nullable. */
+int uavtrack_step_many(uavtrack_env *env, int32_t T, const int32_t *actions,
+                       float *obs, float *reward, float *terms,
+                       int32_t *covered, uint8_t *done, float *ep_sums, void *stream);
+
+/* Launch geometry of the step kernel, for reports: out[0] = workgroup size,
+ * out[1] = envs per workgroup, out[2] = workgroups, out[3] = LDS bytes per
+ * workgroup, out[4] = 1 if a compile-time-specialised (N, M) variant is used. */
+int uavtrack_kernel_info(uavtrack_env *env, int64_t out[5]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UAVTRACK_H */

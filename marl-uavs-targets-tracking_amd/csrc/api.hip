@@ -1,0 +1,326 @@
+// api.hip -- the C ABI of libuavtrack.so (include/uavtrack.h): handle lifetime,
+// argument validation, constant folding, and stream-ordered launches.  No compute
+// happens on the host and there is no CPU fallback.
+
+#include "internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+using namespace uavtrack;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e__ = (expr);                                                       \
+        if (e__ != hipSuccess) return fail("%s: %s", #expr, hipGetErrorString(e__));   \
+    } while (0)
+
+template <typename T>
+hipError_t dmalloc(T **p, size_t n)
+{
+    return hipMalloc(reinterpret_cast<void **>(p), (n ? n : 1) * sizeof(T));
+}
+
+void free_state(uavtrack_env *env)
+{
+    StepParams &s = env->base;
+    void *ptrs[] = {s.ux, s.uy, s.uz, s.uh, s.ua, s.tx, s.ty, s.tz, s.th, s.step_count,
+                    env->pmi.blob, env->pmi_scratch};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+}
+
+int validate(const uavtrack_config &c)
+{
+    if (c.struct_size != sizeof(uavtrack_config))
+        return fail("uavtrack_config.struct_size %u != %zu (ABI mismatch)", c.struct_size, sizeof(uavtrack_config));
+    if (c.n_envs < 1) return fail("n_envs must be >= 1 (got %d)", c.n_envs);
+    if (c.n_uav < 1 || c.n_uav > kMaxWorkgroup) return fail("n_uav must be in [1, %d] (got %d)", kMaxWorkgroup, c.n_uav);
+    if (c.m_targets < 1 || c.m_targets > 4096) return fail("m_targets must be in [1, 4096] (got %d)", c.m_targets);
+    if (c.dim != 2 && c.dim != 3) return fail("dim must be 2 or 3 (got %d)", c.dim);
+    if (c.na < 2) return fail("na must be >= 2 (got %d)", c.na);
+    if (c.nc < 1 || c.nc > UAVTRACK_MAX_CLIMB) return fail("nc must be in [1, %d] (got %d)", UAVTRACK_MAX_CLIMB, c.nc);
+    if (c.dim == 2 && c.nc != 1) return fail("nc must be 1 when dim == 2 (got %d)", c.nc);
+    if (c.norm_n_uav < 1 || c.norm_m_targets < 1) return fail("norm_n_uav / norm_m_targets must be >= 1");
+    if (c.reward_mode < UAVTRACK_REWARD_RAW || c.reward_mode > UAVTRACK_REWARD_PMI)
+        return fail("reward_mode must be 0 (raw), 1 (mean) or 2 (pmi) (got %d)", c.reward_mode);
+    if (c.horizon < 0) return fail("horizon must be >= 0");
+    if (!(c.dc > 0) || !(c.dp > 0) || !(c.u_v_max > 0) || !(c.dt > 0)) return fail("dc, dp, u_v_max, dt must be > 0");
+    if ((int64_t)c.n_envs * c.n_uav * UAVTRACK_OBS_DIM > ((int64_t)1 << 40)) return fail("batch too large");
+    return 0;
+}
+
+void fold_constants(const uavtrack_config &c, StepParams &p)
+{
+    p.B = c.n_envs; p.N = c.n_uav; p.M = c.m_targets;
+    p.na = c.na; p.na_total = c.na * c.nc; p.horizon = c.horizon;
+    p.x_max = (float)c.x_max; p.y_max = (float)c.y_max; p.z_max = (float)c.z_max;
+    p.dtv_u = (float)(c.dt * c.u_v_max);
+    p.dtv_t = (float)(c.dt * c.t_v_max);
+    p.turn_unit = (float)(c.dt * c.u_h_max / (double)(c.na - 1));
+    p.inv_dc = (float)(1.0 / c.dc);
+    p.inv_dp = (float)(1.0 / c.dp);
+    p.dp = (float)c.dp;
+    p.dp2 = (float)(c.dp * c.dp);
+    p.dc2 = (float)(c.dc * c.dc);
+    p.two_dp2 = (float)(4.0 * c.dp * c.dp);
+    p.vratio = (float)(c.t_v_max / c.u_v_max);
+    p.inv_na_total = (float)(1.0 / (double)(c.na * c.nc));
+    const double log2e = 1.4426950408889634;
+    p.exp_k0 = (float)log2e;
+    p.exp_k1 = (float)(log2e / (2.0 * c.dp));
+    p.tt_ceil = (float)(2.0 * c.norm_m_targets);
+    p.inv_tt_ceil = (float)(1.0 / (2.0 * c.norm_m_targets));
+    const double dup_floor = -M_E / 2.0 * c.norm_n_uav;
+    p.dup_floor = (float)dup_floor;
+    p.inv_dup = (float)(1.0 / -dup_floor);
+    p.alpha = (float)c.alpha; p.beta = (float)c.beta; p.gamma = (float)c.gamma;
+    p.coop = (float)c.cooperative;
+    for (int k = 0; k < UAVTRACK_MAX_CLIMB; ++k) {
+        double g = 0.0;
+        if (c.nc > 1 && k < c.nc) g = (2.0 * k - (c.nc - 1)) * c.u_g_max / (double)(c.nc - 1);
+        p.climb_c[k] = (float)std::cos(g);
+        p.climb_s[k] = (float)std::sin(g);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int uavtrack_version(void) { return UAVTRACK_ABI_VERSION; }
+
+const char *uavtrack_last_error(void) { return g_err.c_str(); }
+
+int uavtrack_create(const uavtrack_config *cfg, uavtrack_env **out)
+{
+    if (!cfg || !out) return fail("uavtrack_create: null argument");
+    *out = nullptr;
+    if (validate(*cfg)) return 1;
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return fail("uavtrack_create: no HIP device visible (%s); libuavtrack has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev)
+        return fail("uavtrack_create: device_id %d out of range [0, %d)", cfg->device_id, ndev);
+    HIP_TRY(hipSetDevice(cfg->device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail("uavtrack_create: device %d is %s; this library is built for gfx950 only", cfg->device_id,
+                    prop.gcnArchName);
+
+    uavtrack_env *env = new (std::nothrow) uavtrack_env();
+    if (!env) return fail("uavtrack_create: out of host memory");
+    env->cfg = *cfg;
+    memset(&env->base, 0, sizeof env->base);
+    fold_constants(*cfg, env->base);
+    env->geo = plan_geometry(*cfg);
+    if (env->geo.wgs == 0) {
+        delete env;
+        return fail("uavtrack_create: no workgroup geometry for n_uav=%d", cfg->n_uav);
+    }
+    env->base.E = env->geo.envs_per_wg;
+    if (env->geo.lds_bytes > 64 * 1024) {
+        const size_t need = env->geo.lds_bytes;
+        delete env;
+        return fail("uavtrack_create: LDS need %zu B exceeds the 64 KiB this build launches with (n_uav=%d, m_targets=%d)", need, cfg->n_uav,
+                    cfg->m_targets);
+    }
+
+    StepParams &s = env->base;
+    const size_t BN = (size_t)cfg->n_envs * cfg->n_uav, BM = (size_t)cfg->n_envs * cfg->m_targets;
+    hipError_t err = hipSuccess;
+    auto keep = [&](hipError_t r) { if (err == hipSuccess) err = r; };
+    keep(dmalloc(&s.ux, BN)); keep(dmalloc(&s.uy, BN)); keep(dmalloc(&s.uh, BN)); keep(dmalloc(&s.ua, BN));
+    keep(dmalloc(&s.tx, BM)); keep(dmalloc(&s.ty, BM)); keep(dmalloc(&s.th, BM));
+    keep(dmalloc(&s.step_count, (size_t)cfg->n_envs));
+    if (cfg->dim == 3) { keep(dmalloc(&s.uz, BN)); keep(dmalloc(&s.tz, BM)); }
+    if (err == hipSuccess) {
+        keep(hipMemset(s.ux, 0, BN * 4)); keep(hipMemset(s.uy, 0, BN * 4)); keep(hipMemset(s.uh, 0, BN * 4));
+        keep(hipMemset(s.ua, 0, BN * 4));
+        keep(hipMemset(s.tx, 0, (BM ? BM : 1) * 4)); keep(hipMemset(s.ty, 0, (BM ? BM : 1) * 4));
+        keep(hipMemset(s.th, 0, (BM ? BM : 1) * 4));
+        keep(hipMemset(s.step_count, 0, (size_t)cfg->n_envs * 4));
+        if (cfg->dim == 3) { keep(hipMemset(s.uz, 0, BN * 4)); keep(hipMemset(s.tz, 0, (BM ? BM : 1) * 4)); }
+    }
+    if (err != hipSuccess) {
+        free_state(env);
+        delete env;
+        return fail("uavtrack_create: device allocation failed: %s", hipGetErrorString(err));
+    }
+    *out = env;
+    return 0;
+}
+
+int uavtrack_destroy(uavtrack_env *env)
+{
+    if (!env) return 0;
+    (void)hipSetDevice(env->cfg.device_id);
+    free_state(env);
+    delete env;
+    return 0;
+}
+
+int uavtrack_reset(uavtrack_env *env, uint64_t seed, uint32_t episode, float *obs, void *stream)
+{
+    if (!env) return fail("uavtrack_reset: null handle");
+    HIP_TRY(hipSetDevice(env->cfg.device_id));
+    HIP_TRY(launch_reset(env, seed, episode, obs, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int uavtrack_set_state(uavtrack_env *env, const float *ux, const float *uy, const float *uz, const float *uh,
+                       const int32_t *ua, const float *tx, const float *ty, const float *tz, const float *th,
+                       const int32_t *step_count, void *stream)
+{
+    if (!env) return fail("uavtrack_set_state: null handle");
+    if (!ux || !uy || !uh || !ua) return fail("uavtrack_set_state: null UAV array");
+    const uavtrack_config &c = env->cfg;
+    if (c.m_targets > 0 && (!tx || !ty || !th)) return fail("uavtrack_set_state: null target array");
+    if (c.dim == 3 && (!uz || (c.m_targets > 0 && !tz))) return fail("uavtrack_set_state: dim == 3 needs uz and tz");
+    HIP_TRY(hipSetDevice(c.device_id));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    StepParams &s = env->base;
+    const size_t BN = (size_t)c.n_envs * c.n_uav * 4, BM = (size_t)c.n_envs * c.m_targets * 4;
+    HIP_TRY(hipMemcpyAsync(s.ux, ux, BN, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s.uy, uy, BN, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s.uh, uh, BN, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s.ua, ua, BN, hipMemcpyDeviceToDevice, st));
+    if (BM) {
+        HIP_TRY(hipMemcpyAsync(s.tx, tx, BM, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(s.ty, ty, BM, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(s.th, th, BM, hipMemcpyDeviceToDevice, st));
+    }
+    if (c.dim == 3) {
+        HIP_TRY(hipMemcpyAsync(s.uz, uz, BN, hipMemcpyDeviceToDevice, st));
+        if (BM) HIP_TRY(hipMemcpyAsync(s.tz, tz, BM, hipMemcpyDeviceToDevice, st));
+    }
+    if (step_count)
+        HIP_TRY(hipMemcpyAsync(s.step_count, step_count, (size_t)c.n_envs * 4, hipMemcpyDeviceToDevice, st));
+    else
+        HIP_TRY(hipMemsetAsync(s.step_count, 0, (size_t)c.n_envs * 4, st));
+    return 0;
+}
+
+int uavtrack_get_state(uavtrack_env *env, float *ux, float *uy, float *uz, float *uh, int32_t *ua, float *tx,
+                       float *ty, float *tz, float *th, int32_t *step_count, void *stream)
+{
+    if (!env) return fail("uavtrack_get_state: null handle");
+    const uavtrack_config &c = env->cfg;
+    HIP_TRY(hipSetDevice(c.device_id));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    StepParams &s = env->base;
+    const size_t BN = (size_t)c.n_envs * c.n_uav * 4, BM = (size_t)c.n_envs * c.m_targets * 4;
+    if (ux) HIP_TRY(hipMemcpyAsync(ux, s.ux, BN, hipMemcpyDeviceToDevice, st));
+    if (uy) HIP_TRY(hipMemcpyAsync(uy, s.uy, BN, hipMemcpyDeviceToDevice, st));
+    if (uh) HIP_TRY(hipMemcpyAsync(uh, s.uh, BN, hipMemcpyDeviceToDevice, st));
+    if (ua) HIP_TRY(hipMemcpyAsync(ua, s.ua, BN, hipMemcpyDeviceToDevice, st));
+    if (BM) {
+        if (tx) HIP_TRY(hipMemcpyAsync(tx, s.tx, BM, hipMemcpyDeviceToDevice, st));
+        if (ty) HIP_TRY(hipMemcpyAsync(ty, s.ty, BM, hipMemcpyDeviceToDevice, st));
+        if (th) HIP_TRY(hipMemcpyAsync(th, s.th, BM, hipMemcpyDeviceToDevice, st));
+    }
+    if (c.dim == 3) {
+        if (uz) HIP_TRY(hipMemcpyAsync(uz, s.uz, BN, hipMemcpyDeviceToDevice, st));
+        if (tz && BM) HIP_TRY(hipMemcpyAsync(tz, s.tz, BM, hipMemcpyDeviceToDevice, st));
+    }
+    if (step_count)
+        HIP_TRY(hipMemcpyAsync(step_count, s.step_count, (size_t)c.n_envs * 4, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_floats, int32_t hidden, void *stream)
+{
+    if (!env) return fail("uavtrack_set_pmi_weights: null handle");
+    HIP_TRY(hipSetDevice(env->cfg.device_id));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!folded) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (env->pmi.blob) (void)hipFree(env->pmi.blob);
+        env->pmi = PmiWeights();
+        return 0;
+    }
+    if (hidden < 1 || hidden > 1024) return fail("uavtrack_set_pmi_weights: hidden must be in [1, 1024]");
+    const size_t H = (size_t)hidden;
+    const size_t want = 12 * H + 3 * H + 3 * H * H + H + H + 1;
+    if (n_floats != want)
+        return fail("uavtrack_set_pmi_weights: n_floats %zu != %zu for hidden %d", n_floats, want, hidden);
+    if (env->pmi.n_floats != n_floats) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (env->pmi.blob) (void)hipFree(env->pmi.blob);
+        env->pmi = PmiWeights();
+        HIP_TRY(dmalloc(&env->pmi.blob, n_floats));
+    }
+    // pageable host source: the copy is staged before this returns, so `folded` may be freed by the caller
+    HIP_TRY(hipMemcpyAsync(env->pmi.blob, folded, n_floats * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    env->pmi.hidden = hidden;
+    env->pmi.n_floats = n_floats;
+    return 0;
+}
+
+static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float *obs, float *reward, float *terms,
+                     int32_t *covered, uint8_t *done, float *ep_sums, void *stream, const char *who)
+{
+    if (!env) return fail("%s: null handle", who);
+    if (T < 1) return fail("%s: T must be >= 1 (got %d)", who, T);
+    if (!actions) return fail("%s: actions is null", who);
+    if (!reward) return fail("%s: reward is null", who);
+    if (env->cfg.reward_mode == UAVTRACK_REWARD_PMI)
+        return fail("%s: reward_mode PMI is not implemented in this build", who);
+    HIP_TRY(hipSetDevice(env->cfg.device_id));
+    StepParams p = env->base;
+    p.T = T;
+    p.actions = actions;
+    p.obs = obs; p.reward = reward; p.terms = terms; p.raw_out = nullptr;
+    p.covered = covered; p.done = done; p.ep_sums = ep_sums;
+    HIP_TRY(launch_rollout(env, p, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int uavtrack_step(uavtrack_env *env, const int32_t *actions, float *obs, float *reward, float *terms,
+                  int32_t *covered, uint8_t *done, void *stream)
+{
+    return run_steps(env, 1, actions, obs, reward, terms, covered, done, nullptr, stream, "uavtrack_step");
+}
+
+int uavtrack_step_many(uavtrack_env *env, int32_t T, const int32_t *actions, float *obs, float *reward,
+                       float *terms, int32_t *covered, uint8_t *done, float *ep_sums, void *stream)
+{
+    return run_steps(env, T, actions, obs, reward, terms, covered, done, ep_sums, stream, "uavtrack_step_many");
+}
+
+int uavtrack_kernel_info(uavtrack_env *env, int64_t out[5])
+{
+    if (!env || !out) return fail("uavtrack_kernel_info: null argument");
+    out[0] = env->geo.wgs;
+    out[1] = env->geo.envs_per_wg;
+    out[2] = env->geo.groups;
+    out[3] = (int64_t)env->geo.lds_bytes;
+    out[4] = env->geo.specialised;
+    return 0;
+}
+
+}  // extern "C"

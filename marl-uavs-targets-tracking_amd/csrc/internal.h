@@ -1,0 +1,82 @@
+// internal.h -- shared between the C-ABI translation unit and the kernel files.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "uavtrack.h"
+
+namespace uavtrack {
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kTwoPi = 6.28318530717958647692f;
+constexpr int kMaxWorkgroup = 512;   // __launch_bounds__ of the rollout kernel
+
+// Kernel arguments of one rollout launch (T >= 1 steps).  All pointers are device
+// pointers.  Derived constants are computed once on the host in fp64, then cast.
+struct StepParams {
+    // state, SoA over (env, uav) and (env, target); updated in place
+    float *ux, *uy, *uz, *uh;
+    int32_t *ua;
+    float *tx, *ty, *tz, *th;
+    int32_t *step_count;
+    // per-step I/O, leading [T] axis
+    const int32_t *actions;
+    float *obs, *reward, *terms, *raw_out;
+    int32_t *covered;
+    uint8_t *done;
+    float *ep_sums;
+    // geometry
+    int32_t B, N, M, E, T, na, na_total, horizon;
+    // constants
+    float x_max, y_max, z_max;
+    float dtv_u, dtv_t;          // dt * v_max of UAVs / targets
+    float turn_unit;             // dt * h_max / (na - 1)        (uav.py:81,96)
+    float inv_dc, inv_dp, dp, dp2, dc2, two_dp2;
+    float vratio;                // target.v_max / uav.v_max      (uav.py:116)
+    float inv_na_total;
+    float exp_k0, exp_k1;        // exp((2dp-d)/(2dp)) = exp2(k0 - k1*d)   (uav.py:226)
+    float tt_ceil, inv_tt_ceil;  // 2*m_targets                   (environment.py:208)
+    float dup_floor, inv_dup;    // -e/2*n_uav and 1/(e/2*n_uav)  (environment.py:210)
+    float alpha, beta, gamma, coop;
+    float climb_c[UAVTRACK_MAX_CLIMB], climb_s[UAVTRACK_MAX_CLIMB];   // cos/sin of the climb angles
+};
+
+struct PmiWeights {
+    float *blob = nullptr;   // device, folded layout of uavtrack_set_pmi_weights
+    int32_t hidden = 0;
+    size_t n_floats = 0;
+};
+
+struct Geometry {
+    int wgs = 0;          // threads per workgroup
+    int envs_per_wg = 0;  // E
+    int groups = 0;       // workgroups
+    size_t lds_bytes = 0;
+    int specialised = 0;
+};
+
+}  // namespace uavtrack
+
+struct uavtrack_env {
+    uavtrack_config cfg;
+    uavtrack::StepParams base;   // constants + state pointers filled at create
+    uavtrack::Geometry geo;
+    uavtrack::PmiWeights pmi;
+    // PMI scratch (allocated on first use)
+    void *pmi_scratch = nullptr;
+    size_t pmi_scratch_bytes = 0;
+};
+
+namespace uavtrack {
+
+// step_kernel.hip
+Geometry plan_geometry(const uavtrack_config &cfg);
+hipError_t launch_rollout(const uavtrack_env *env, const StepParams &p, hipStream_t stream);
+
+// reset_kernel.hip
+hipError_t launch_reset(const uavtrack_env *env, uint64_t seed, uint32_t episode, float *obs,
+                        hipStream_t stream);
+
+}  // namespace uavtrack

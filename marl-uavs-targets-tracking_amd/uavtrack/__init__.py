@@ -1,0 +1,16 @@
+"""uavtrack -- MI355X-native batched multi-UAV target-tracking environment.
+
+Host side (Python, like the reference) of the C-ABI library libuavtrack.so whose HIP
+kernels replace the reset/step path of the reference's src/environment.py.
+There is no CPU fallback: without the built library and a gfx950 GPU every
+compute entry point raises.
+"""
+from .config import EnvConfig, RewardMode  # noqa: F401
+from .env import BatchedUavEnv  # noqa: F401
+from .compat import Environment  # noqa: F401
+from .pmi import fold_pmi_state_dict  # noqa: F401
+from .sharding import shard_range, gather_rollout_summary  # noqa: F401
+from . import _lib  # noqa: F401
+
+__all__ = ["EnvConfig", "RewardMode", "BatchedUavEnv", "Environment", "fold_pmi_state_dict",
+           "shard_range", "gather_rollout_summary"]

@@ -1,0 +1,176 @@
+"""Drop-in stand-in for the reference's `Environment` class (src/environment.py:12), so
+that train.operate_epoch-style loops and the MAAC / MAAC-R actors run unchanged:
+
+    env = Environment(n_uav=, m_targets=, x_max=, y_max=, na=)      # main.py:55-59
+    env.reset(config=config)                                         # train.py:232,311,383
+    for uav in env.uav_list: state = uav.get_local_state()           # train.py:165-166
+    next_states, reward, covered = env.step(config, pmi, actions)    # train.py:176
+    env.n_uav, env.get_states(), env.position, env.covered_target_num,
+    env.save_position(dir, i), env.save_covered_num(dir, i)          # train.py:187,287-288
+
+One reference environment is a batch of one on the GPU; every number it returns comes
+from the HIP kernels through the C ABI (uavtrack.BatchedUavEnv).  `n_envs > 1` keeps the
+same call shapes for env 0 while stepping a whole batch with shared actions -- useful
+only for smoke checks; batched training should use BatchedUavEnv directly.
+"""
+from __future__ import annotations
+
+import os
+import random
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from .config import EnvConfig, RewardMode
+from .env import BatchedUavEnv
+
+
+class _UavView:
+    """What the callers touch on `env.uav_list[i]` (uav.py:12-51 attributes, :192)."""
+
+    def __init__(self, env: "Environment", i: int):
+        self._env, self._i = env, i
+
+    def get_local_state(self) -> np.ndarray:
+        return self._env._obs[self._i].copy()
+
+    x = property(lambda self: float(self._env._host_state()["ux"][self._i]))
+    y = property(lambda self: float(self._env._host_state()["uy"][self._i]))
+    h = property(lambda self: float(self._env._host_state()["uh"][self._i]))
+    a = property(lambda self: int(self._env._host_state()["ua"][self._i]))
+    dp = property(lambda self: self._env._cfg.dp)
+    dc = property(lambda self: self._env._cfg.dc)
+    raw_reward = property(lambda self: None)
+    reward = property(lambda self: float(self._env._last_reward[self._i]))
+
+
+class _TargetView:
+    def __init__(self, env: "Environment", k: int):
+        self._env, self._k = env, k
+
+    x = property(lambda self: float(self._env._host_state()["tx"][self._k]))
+    y = property(lambda self: float(self._env._host_state()["ty"][self._k]))
+    h = property(lambda self: float(self._env._host_state()["th"][self._k]))
+
+
+class Environment:
+    def __init__(self, n_uav: int, m_targets: int, x_max: float, y_max: float, na: int,
+                 device: str = "cuda:0"):
+        self.x_max, self.y_max = x_max, y_max
+        self.state_dim = (4 + 1) + 4 + (2 + 1)      # environment.py:28
+        self.action_dim = na
+        self.n_uav, self.m_targets = n_uav, m_targets
+        self.uav_list: List[_UavView] = []
+        self.target_list: List[_TargetView] = []
+        self.position = {'all_uav_xs': [], 'all_uav_ys': [], 'all_target_xs': [], 'all_target_ys': []}
+        self.covered_target_num: List[int] = []
+        self._device = device
+        self._env: Optional[BatchedUavEnv] = None
+        self._cfg: Optional[EnvConfig] = None
+        self._obs = np.zeros((n_uav, 12), dtype=np.float64)
+        self._last_reward = np.zeros(n_uav)
+        self._state_cache = None
+        self._pmi_id = None
+        self._episode = 0
+
+    # -- helpers ----------------------------------------------------------------------
+    def _mode_for(self, config, pmi) -> RewardMode:
+        if float(config.get('cooperative', 0)) == 0:
+            return RewardMode.RAW                     # uav.py:270,300
+        return RewardMode.PMI if pmi else RewardMode.MEAN   # uav.py:319
+
+    def _make(self, config, mode: RewardMode):
+        cfg = EnvConfig.from_reference_dict(config, n_envs=1, reward_mode=mode, horizon=0)
+        # the env object's own sizes rule the simulation; config's n_uav/m_targets only
+        # enter the reward normalisation (environment.py:208-210)
+        cfg = cfg.with_(n_uav=self.n_uav, m_targets=self.m_targets, x_max=float(self.x_max),
+                        y_max=float(self.y_max), na=int(self.action_dim),
+                        norm_n_uav=int(config['environment']['n_uav']),
+                        norm_m_targets=int(config['environment']['m_targets']))
+        return cfg
+
+    def _ensure(self, config, mode: RewardMode):
+        cfg = self._make(config, mode)
+        if self._env is None or cfg != self._cfg:
+            state = self._env.get_state() if self._env is not None else None
+            if self._env is not None:
+                self._env.close()
+            self._env = BatchedUavEnv(cfg, device=self._device)
+            self._cfg = cfg
+            self._pmi_id = None
+            if state is not None:
+                self._env.set_state(**state)
+
+    def _host_state(self):
+        if self._state_cache is None:
+            s = self._env.get_state()
+            self._state_cache = {k: v[0].cpu().numpy() for k, v in s.items() if k != "step_count"}
+        return self._state_cache
+
+    # -- reference surface ------------------------------------------------------------
+    def reset(self, config):
+        """environment.py:87-107.  Returns None like the reference.  The seed is drawn from
+        Python's `random`, so `random.seed(42)` (args_util.py:18-21) still pins a run."""
+        self._ensure(config, self._mode_for(config, None) if self._cfg is None else self._cfg.resolved_mode())
+        seed = random.getrandbits(63)
+        obs = self._env.reset(seed=seed, episode=self._episode)
+        self._episode += 1
+        self._obs = obs[0].double().cpu().numpy()
+        self._state_cache = None
+        self.uav_list = [_UavView(self, i) for i in range(self.n_uav)]
+        self.target_list = [_TargetView(self, k) for k in range(self.m_targets)]
+        self.position = {'all_uav_xs': [], 'all_uav_ys': [], 'all_target_xs': [], 'all_target_ys': []}
+        self.covered_target_num = []
+
+    def get_states(self) -> List[np.ndarray]:
+        return [self._obs[i].copy() for i in range(self.n_uav)]   # environment.py:109-118
+
+    def step(self, config, pmi, actions):
+        mode = self._mode_for(config, pmi)
+        self._ensure(config, mode)
+        if mode == RewardMode.PMI and (id(pmi) != self._pmi_id or not self.covered_target_num):
+            self._env.set_pmi(pmi.state_dict())   # weights change between episodes (train.py:262)
+            self._pmi_id = id(pmi)
+        a = torch.as_tensor(np.asarray(actions, dtype=np.int32).reshape(1, self.n_uav))
+        obs, reward, _ = self._env.step(a)
+        terms = self._env.info["terms"][:, 0].double().cpu().numpy()
+        covered = int(self._env.info["covered"][0].item())
+        self._obs = obs[0].double().cpu().numpy()
+        self._last_reward = reward[0].double().cpu().numpy()
+        self._state_cache = None
+        st = self._host_state()
+        self.covered_target_num.append(covered)                      # environment.py:147
+        self.position['all_target_xs'].append(st["tx"].tolist())     # environment.py:150-155
+        self.position['all_target_ys'].append(st["ty"].tolist())
+        self.position['all_uav_xs'].append(st["ux"].tolist())
+        self.position['all_uav_ys'].append(st["uy"].tolist())
+        reward_dict = {                                              # environment.py:157-162
+            'rewards': self._last_reward.tolist(),
+            'target_tracking_reward': terms[0].tolist(),
+            'boundary_punishment': terms[1].tolist(),
+            'duplicate_tracking_punishment': terms[2].tolist(),
+        }
+        return self.get_states(), reward_dict, covered
+
+    def get_uav_and_target_position(self):
+        return (self.position['all_uav_xs'], self.position['all_uav_ys'],
+                self.position['all_target_xs'], self.position['all_target_ys'])   # environment.py:188-193
+
+    def calculate_covered_target(self) -> int:
+        return self.covered_target_num[-1] if self.covered_target_num else 0
+
+    def save_position(self, save_dir, epoch_i):
+        """Same CSV layout as environment.py:229-238."""
+        u_xy = np.array([self.position["all_uav_xs"], self.position["all_uav_ys"]]).transpose()
+        t_xy = np.array([self.position["all_target_xs"], self.position["all_target_ys"]]).transpose()
+        np.savetxt(os.path.join(save_dir, "u_xy", 'u_xy' + str(epoch_i) + '.csv'),
+                   u_xy.reshape(-1, 2), delimiter=',', header='x,y', comments='')
+        np.savetxt(os.path.join(save_dir, "t_xy", 't_xy' + str(epoch_i) + '.csv'),
+                   t_xy.reshape(-1, 2), delimiter=',', header='x,y', comments='')
+
+    def save_covered_num(self, save_dir, epoch_i):
+        """environment.py:240-244."""
+        arr = np.array(self.covered_target_num).reshape(-1, 1)
+        np.savetxt(os.path.join(save_dir, "covered_target_num", 'covered_target_num' + str(epoch_i) + '.csv'),
+                   arr, delimiter=',', header='covered_target_num', comments='')

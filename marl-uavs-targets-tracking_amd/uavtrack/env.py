@@ -1,0 +1,179 @@
+"""BatchedUavEnv: the batched reset()/step(actions) -> (obs, reward, done) surface over
+libuavtrack.so.  Tensors are torch-ROCm device tensors owned by Python; the kernels
+write them in place on torch's current stream (no host sync, no copies)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import EnvConfig, RewardMode
+from .pmi import fold_pmi_state_dict
+
+_STATE_KEYS = ("ux", "uy", "uz", "uh", "ua", "tx", "ty", "tz", "th")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class BatchedUavEnv:
+    """B independent copies of the reference `Environment` (src/environment.py:12) on one GPU.
+
+    reset(seed)            -> obs [B, N, 12]                           (environment.py:87-118)
+    step(actions [B, N])   -> (obs [B, N, 12], reward [B, N], done [B]) (environment.py:120-164)
+                              self.info = {"terms": [3, B, N], "covered": [B]}
+    step_many(actions [T, B, N]) -> dict with a leading T axis, one launch
+    """
+
+    def __init__(self, cfg: EnvConfig, device: str = "cuda:0"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("uavtrack runs on an MI355X only (device must be cuda:N); there is no CPU path")
+        self._lib = _lib.load()
+        idx = self.device.index if self.device.index is not None else 0
+        self._device_index = idx
+        cstruct = cfg.c_struct(idx)
+        handle = C.c_void_p()
+        _lib.check(self._lib.uavtrack_create(C.byref(cstruct), C.byref(handle)), "uavtrack_create")
+        self._h = handle
+        self.info: Dict[str, torch.Tensor] = {}
+        self._episode = 0
+
+    # -- plumbing ---------------------------------------------------------------------
+    @property
+    def B(self) -> int: return self.cfg.n_envs
+    @property
+    def N(self) -> int: return self.cfg.n_uav
+    @property
+    def M(self) -> int: return self.cfg.m_targets
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def _actions(self, actions, shape) -> torch.Tensor:
+        a = torch.as_tensor(actions)
+        if a.device != self.device or a.dtype != torch.int32:
+            a = a.to(device=self.device, dtype=torch.int32)
+        if tuple(a.shape) != tuple(shape):
+            raise ValueError(f"actions shape {tuple(a.shape)} != {tuple(shape)}")
+        return a.contiguous()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.uavtrack_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def kernel_info(self) -> Dict[str, int]:
+        out = (C.c_int64 * 5)()
+        _lib.check(self._lib.uavtrack_kernel_info(self._h, out), "uavtrack_kernel_info")
+        return dict(workgroup=out[0], envs_per_workgroup=out[1], workgroups=out[2], lds_bytes=out[3],
+                    specialised=out[4])
+
+    # -- reference surface ------------------------------------------------------------
+    def reset(self, seed: int = 0, episode: Optional[int] = None) -> torch.Tensor:
+        if episode is None:
+            episode = self._episode
+        self._episode = episode + 1
+        obs = self._empty((self.B, self.N, _lib.OBS_DIM), torch.float32)
+        _lib.check(self._lib.uavtrack_reset(self._h, C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint32(episode),
+                                            _ptr(obs), self._stream()), "uavtrack_reset")
+        return obs
+
+    def step(self, actions, want_terms: bool = True):
+        a = self._actions(actions, (self.B, self.N))
+        obs = self._empty((self.B, self.N, _lib.OBS_DIM), torch.float32)
+        reward = self._empty((self.B, self.N), torch.float32)
+        terms = self._empty((3, self.B, self.N), torch.float32) if want_terms else None
+        covered = self._empty((self.B,), torch.int32)
+        done = self._empty((self.B,), torch.uint8)
+        _lib.check(self._lib.uavtrack_step(self._h, _ptr(a), _ptr(obs), _ptr(reward), _ptr(terms),
+                                           _ptr(covered), _ptr(done), self._stream()), "uavtrack_step")
+        self.info = {"terms": terms, "covered": covered}
+        return obs, reward, done.bool()
+
+    def step_many(self, actions, want_obs: bool = True, want_terms: bool = True, want_ep_sums: bool = True,
+                  out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """T steps in one launch; `actions` is [T, B, N].  Pass the previous result as
+        `out` to reuse its buffers."""
+        a = torch.as_tensor(actions)
+        T = int(a.shape[0])
+        a = self._actions(a, (T, self.B, self.N))
+        o = out or {}
+
+        def buf(key, shape, dtype, want=True):
+            if not want:
+                return None
+            t = o.get(key)
+            if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+                t = self._empty(shape, dtype)
+            return t
+
+        obs = buf("obs", (T, self.B, self.N, _lib.OBS_DIM), torch.float32, want_obs)
+        reward = buf("reward", (T, self.B, self.N), torch.float32)
+        terms = buf("terms", (T, 3, self.B, self.N), torch.float32, want_terms)
+        covered = buf("covered", (T, self.B), torch.int32)
+        done = buf("done", (T, self.B), torch.uint8)
+        ep = buf("ep_sums", (self.B, 5), torch.float32, want_ep_sums)
+        _lib.check(self._lib.uavtrack_step_many(self._h, C.c_int32(T), _ptr(a), _ptr(obs), _ptr(reward),
+                                                _ptr(terms), _ptr(covered), _ptr(done), _ptr(ep),
+                                                self._stream()), "uavtrack_step_many")
+        return dict(obs=obs, reward=reward, terms=terms, covered=covered, done=done, ep_sums=ep)
+
+    # -- state injection / checkpoint -------------------------------------------------
+    def get_state(self) -> Dict[str, torch.Tensor]:
+        three = self.cfg.dim == 3
+        s = dict(ux=self._empty((self.B, self.N), torch.float32), uy=self._empty((self.B, self.N), torch.float32),
+                 uz=self._empty((self.B, self.N), torch.float32) if three else None,
+                 uh=self._empty((self.B, self.N), torch.float32), ua=self._empty((self.B, self.N), torch.int32),
+                 tx=self._empty((self.B, self.M), torch.float32), ty=self._empty((self.B, self.M), torch.float32),
+                 tz=self._empty((self.B, self.M), torch.float32) if three else None,
+                 th=self._empty((self.B, self.M), torch.float32),
+                 step_count=self._empty((self.B,), torch.int32))
+        _lib.check(self._lib.uavtrack_get_state(self._h, *[_ptr(s[k]) for k in _STATE_KEYS],
+                                                _ptr(s["step_count"]), self._stream()), "uavtrack_get_state")
+        return {k: v for k, v in s.items() if v is not None}
+
+    def set_state(self, ux, uy, uh, ua, tx, ty, th, uz=None, tz=None, step_count=None) -> None:
+        def f(v, shape, dtype):
+            if v is None:
+                return None
+            t = torch.as_tensor(np.asarray(v) if not torch.is_tensor(v) else v)
+            t = t.to(device=self.device, dtype=dtype).reshape(shape).contiguous()
+            return t
+        BN, BM = (self.B, self.N), (self.B, self.M)
+        arrs = dict(ux=f(ux, BN, torch.float32), uy=f(uy, BN, torch.float32), uz=f(uz, BN, torch.float32),
+                    uh=f(uh, BN, torch.float32), ua=f(ua, BN, torch.int32),
+                    tx=f(tx, BM, torch.float32), ty=f(ty, BM, torch.float32), tz=f(tz, BM, torch.float32),
+                    th=f(th, BM, torch.float32))
+        sc = f(step_count, (self.B,), torch.int32)
+        _lib.check(self._lib.uavtrack_set_state(self._h, *[_ptr(arrs[k]) for k in _STATE_KEYS], _ptr(sc),
+                                                self._stream()), "uavtrack_set_state")
+        # the D2D copies are stream-ordered; keep the sources alive until they have run
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def set_pmi(self, state_dict) -> None:
+        """state_dict of a reference PMINetwork (or None to disable)."""
+        if state_dict is None:
+            _lib.check(self._lib.uavtrack_set_pmi_weights(self._h, None, 0, 0, self._stream()), "set_pmi")
+            return
+        blob, hidden = fold_pmi_state_dict(state_dict)
+        _lib.check(self._lib.uavtrack_set_pmi_weights(self._h, C.c_void_p(blob.ctypes.data), blob.size, hidden,
+                                                      self._stream()), "uavtrack_set_pmi_weights")
+
+    @property
+    def reward_mode(self) -> RewardMode:
+        return self.cfg.resolved_mode()

@@ -1,0 +1,277 @@
+"""GPU parity: the HIP path, called through the C ABI, against the fp64 CPU oracle and
+against golden vectors recorded from the unmodified reference.
+
+Tolerances (BASELINE.json north_star): indices (actions, covered counts) bit-exact;
+fp32 observations / rewards within 1e-5 absolute (they are normalised to O(1)); poses
+within 1e-5 relative (fp32 ulp at 2000 m is 1.2e-4 m, so an absolute 1e-5 on metres is
+not representable).  Range tests (d <= dp, d <= dc, d <= 2dp, d < dp, wall crossings)
+are discontinuous: an environment whose fp64 margin |d - threshold| is below 1e-3 this
+step may legitimately flip in fp32, so such environments are excluded per step (and
+counted -- they must stay rare).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import OracleConfig, OracleEnv
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-5
+RTOL_POSE = 1e-5
+MARGIN = 1e-3
+
+
+@pytest.fixture(scope="module")
+def uavtrack():
+    import uavtrack
+    return uavtrack
+
+
+def ang_diff(a, b):
+    return np.abs((np.asarray(a, np.float64) - np.asarray(b, np.float64) + np.pi) % (2 * np.pi) - np.pi)
+
+
+def host(d):
+    return {k: v.cpu().numpy() for k, v in d.items()}
+
+
+def inject(orc, st):
+    orc.set_state(st["ux"], st["uy"], st["uh"], st["ua"], st["tx"], st["ty"], st["th"],
+                  uz=st.get("uz"), tz=st.get("tz"))
+
+
+def compare_step(env, orc, act, what, margin=MARGIN, min_ok_frac=0.97):
+    """One teacher-forced step: oracle starts from the device's fp32 state."""
+    inject(orc, host(env.get_state()))
+    obs, rew, _ = env.step(torch.from_numpy(act))
+    ref = orc.step(act)
+    ok = ref["margin"] > margin
+    assert ok.mean() >= min_ok_frac, f"{what}: too many knife-edge envs ({ok.mean():.3f})"
+    terms, cov = env.info["terms"].cpu().numpy(), env.info["covered"].cpu().numpy()
+    obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
+    np.testing.assert_allclose(obs[ok], ref["obs"][ok], rtol=0, atol=ATOL, err_msg=f"{what} obs")
+    np.testing.assert_allclose(terms[:, ok], ref["terms"][:, ok], rtol=0, atol=ATOL, err_msg=f"{what} terms")
+    np.testing.assert_allclose(rew[ok], ref["reward"][ok], rtol=0, atol=ATOL, err_msg=f"{what} reward")
+    np.testing.assert_array_equal(cov[ok], ref["covered"][ok], err_msg=f"{what} covered")
+    st, rs = host(env.get_state()), orc.get_state()
+    for k in ("ux", "uy", "tx", "ty") + (("uz",) if "uz" in st else ()):
+        np.testing.assert_allclose(st[k], rs[k], rtol=RTOL_POSE, atol=1e-4, err_msg=f"{what} {k}")
+    assert ang_diff(st["uh"], rs["uh"]).max() < 1e-5, what
+    assert ang_diff(st["th"][ok], rs["th"][ok]).max() < 1e-5, what
+    np.testing.assert_array_equal(st["ua"], rs["ua"])
+    return ok
+
+
+CASES = [
+    # (N, M, cooperative, B)          specialised kernels: (5,3) (10,10) (20,10) (50,25); others generic
+    (5, 3, 0.0, 200), (10, 10, 0.3, 150), (20, 10, 0.0, 256), (20, 10, 0.3, 256),
+    (50, 25, 0.0, 64), (50, 25, 0.3, 64), (7, 4, 0.3, 99), (33, 40, 0.0, 31), (64, 1, 0.3, 9), (1, 5, 0.3, 70),
+    (130, 70, 0.3, 5),
+]
+
+
+@pytest.mark.parametrize("N,M,coop,B", CASES)
+def test_step_teacher_forced_vs_oracle(uavtrack, N, M, coop, B):
+    cfg = uavtrack.EnvConfig(n_envs=B, n_uav=N, m_targets=M, cooperative=coop)
+    env = uavtrack.BatchedUavEnv(cfg)
+    env.reset(seed=1234)
+    orc = OracleEnv(OracleConfig(n_envs=B, n_uav=N, m_targets=M, cooperative=coop), n_threads=8)
+    rng = np.random.RandomState(N * 100 + M)
+    for t in range(6):
+        act = rng.randint(0, 12, size=(B, N)).astype(np.int32)
+        compare_step(env, orc, act, f"N{N} M{M} coop{coop} t{t}")
+    env.close()
+
+
+def test_dense_box_many_neighbours(uavtrack):
+    """Small box: every range test is busy (neighbour counts near N, many tracked targets,
+    UAVs leaving the box)."""
+    kw = dict(n_envs=128, n_uav=20, m_targets=10, cooperative=0.3, x_max=500.0, y_max=400.0)
+    env = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(**kw))
+    env.reset(seed=7)
+    orc = OracleEnv(OracleConfig(**kw), n_threads=8)
+    rng = np.random.RandomState(3)
+    for t in range(25):
+        act = rng.randint(0, 12, size=(128, 20)).astype(np.int32)
+        compare_step(env, orc, act, f"dense t{t}", min_ok_frac=0.5)
+
+
+def test_reset_bitexact_vs_oracle_and_first_obs(uavtrack):
+    for N, M in ((20, 10), (5, 3), (50, 25)):
+        cfg = uavtrack.EnvConfig(n_envs=37, n_uav=N, m_targets=M, env_offset=1000)
+        env = uavtrack.BatchedUavEnv(cfg)
+        obs = env.reset(seed=2 ** 40 + 17, episode=3).cpu().numpy()
+        orc = OracleEnv(OracleConfig(n_envs=37, n_uav=N, m_targets=M))
+        ref_obs = orc.reset_philox(seed=2 ** 40 + 17, episode=3, env_offset=1000)
+        st, rs = host(env.get_state()), orc.get_state()
+        for k in ("ux", "uy", "uh", "tx", "ty", "th"):
+            np.testing.assert_array_equal(st[k].astype(np.float64), rs[k], err_msg=k)
+        np.testing.assert_array_equal(st["ua"], rs["ua"])
+        assert np.all(st["step_count"] == 0)
+        np.testing.assert_allclose(obs, ref_obs, rtol=0, atol=1e-6)
+        assert np.all(obs[..., :9] == -1.0)          # empty observation lists (uav.py:174,186)
+        # reference layout: x_i = i * x_max / (N + 1), y = y_max / 2 (environment.py:105-107)
+        np.testing.assert_allclose(st["ux"][0], np.arange(1, N + 1) * 2000.0 / (N + 1), rtol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["g1_n5m3_raw", "g2_n20m10_raw", "g3_n20m10_mean", "g5a_n50m25_raw"])
+def test_against_reference_goldens(uavtrack, name):
+    """HIP vs the REAL reference's recorded outputs: all (episode, step) pairs of a golden
+    file become one batch, state injected (rounded to fp32), one step, compared."""
+    z, meta = load_golden(name)
+    N, M, coop = meta["n_uav"], meta["m_targets"], meta["cooperative"]
+    E, T = len(meta["seeds"]), meta["steps"]
+    B = E * T
+    pick = lambda k: z[k][:, :T].reshape(B, -1)
+    cfg = uavtrack.EnvConfig(n_envs=B, n_uav=N, m_targets=M, cooperative=coop)
+    env = uavtrack.BatchedUavEnv(cfg)
+    state = {k: pick(k) for k in ("ux", "uy", "uh", "ua", "tx", "ty", "th")}
+    env.set_state(**state)
+    act = z["actions"].reshape(B, N).astype(np.int32)
+    # margins from the oracle started at the same fp32-rounded state
+    orc = OracleEnv(OracleConfig(n_envs=B, n_uav=N, m_targets=M, cooperative=coop), n_threads=8)
+    inject(orc, host(env.get_state()))
+    ok = orc.step(act)["margin"] > 5e-3
+    assert ok.mean() > 0.9
+    obs, rew, _ = env.step(torch.from_numpy(act))
+    obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
+    terms, cov = env.info["terms"].cpu().numpy(), env.info["covered"].cpu().numpy()
+    # inputs were rounded to fp32 (<= 6e-5 m on a pose), hence 2e-5 rather than 1e-5 here
+    np.testing.assert_allclose(obs[ok], z["obs"].reshape(B, N, 12)[ok], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(rew[ok], z["reward"].reshape(B, N)[ok], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(terms[:, ok], np.moveaxis(z["terms"].reshape(B, 3, N), 1, 0)[:, ok], rtol=0, atol=2e-5)
+    np.testing.assert_array_equal(cov[ok], z["covered"].reshape(B)[ok])
+    st = host(env.get_state())
+    nxt = lambda k: z[k][:, 1:T + 1].reshape(B, -1)
+    np.testing.assert_allclose(st["ux"], nxt("ux"), rtol=RTOL_POSE, atol=2e-4)
+    np.testing.assert_allclose(st["uy"], nxt("uy"), rtol=RTOL_POSE, atol=2e-4)
+    assert ang_diff(st["uh"], nxt("uh")).max() < 1e-5
+    np.testing.assert_array_equal(st["ua"], nxt("ua"))
+
+
+def test_edge_cases_exact_thresholds(uavtrack):
+    """g7: hand-placed cases whose distances sit EXACTLY on dp / dc / 2dp and on the walls.
+    The inputs are exactly representable in fp32, so no margin exclusion: every inclusive /
+    strict decision must come out as in the reference."""
+    z, meta = load_golden("g7_edges")
+    for case in meta["cases"]:
+        if case["pmi"]:
+            continue
+        name, N, M = case["name"], case["n_uav"], case["m_targets"]
+        cfg = uavtrack.EnvConfig(n_envs=1, n_uav=N, m_targets=M, cooperative=case["cooperative"])
+        env = uavtrack.BatchedUavEnv(cfg)
+        g = lambda k: z[f"{name}__{k}"]
+        for t in range(case["steps"]):
+            env.set_state(**{k: g(k)[t][None] for k in ("ux", "uy", "uh", "ua", "tx", "ty", "th")})
+            obs, rew, _ = env.step(torch.from_numpy(g("actions")[t][None].astype(np.int32)))
+            tol = 2e-4 if name == "near_origin_weight" else 2e-5   # 1/w with w ~ 0.14 amplifies fp32 rounding
+            np.testing.assert_allclose(obs[0].cpu().numpy(), g("obs")[t], rtol=0, atol=tol, err_msg=f"{name} obs t{t}")
+            np.testing.assert_allclose(rew[0].cpu().numpy(), g("reward")[t], rtol=0, atol=2e-5, err_msg=f"{name} rew t{t}")
+            np.testing.assert_allclose(env.info["terms"][:, 0].cpu().numpy(), g("terms")[t], rtol=0, atol=2e-5,
+                                       err_msg=f"{name} terms t{t}")
+            assert int(env.info["covered"][0]) == int(g("covered")[t]), f"{name} covered t{t}"
+            st = host(env.get_state())
+            assert ang_diff(st["th"][0], g("th")[t + 1]).max() < 1e-5, f"{name} th t{t}"
+            assert ang_diff(st["uh"][0], g("uh")[t + 1]).max() < 1e-5, f"{name} uh t{t}"
+            np.testing.assert_allclose(st["tx"][0], g("tx")[t + 1], rtol=1e-6, atol=1e-4)
+
+
+def test_step_many_bitwise_equals_single_steps(uavtrack):
+    for N, M, coop in ((20, 10, 0.0), (20, 10, 0.3), (50, 25, 0.3), (7, 4, 0.0)):
+        T, B = 37, 50
+        cfg = uavtrack.EnvConfig(n_envs=B, n_uav=N, m_targets=M, cooperative=coop, horizon=30,
+                                 x_max=800.0, y_max=700.0)   # small box: targets bounce within T steps
+        a = uavtrack.BatchedUavEnv(cfg); b = uavtrack.BatchedUavEnv(cfg)
+        a.reset(seed=5); b.reset(seed=5)
+        act = torch.randint(0, 12, (T, B, N), dtype=torch.int32, device="cuda", generator=torch.Generator("cuda").manual_seed(1))
+        many = a.step_many(act)
+        ep = torch.zeros(B, 5, device="cuda")
+        for t in range(T):
+            obs, rew, done = b.step(act[t])
+            assert torch.equal(obs, many["obs"][t]) and torch.equal(rew, many["reward"][t])
+            assert torch.equal(b.info["terms"], many["terms"][t])
+            assert torch.equal(b.info["covered"], many["covered"][t])
+            assert torch.equal(done, many["done"][t].bool())
+            assert bool(done.all()) == (t + 1 >= 30)
+            ep[:, 0] += rew.mean(1); ep[:, 1:4] += b.info["terms"].mean(2).T; ep[:, 4] += b.info["covered"]
+        sa, sb = a.get_state(), b.get_state()
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), k
+        torch.testing.assert_close(many["ep_sums"], ep, rtol=1e-5, atol=1e-5)
+        assert int(sa["step_count"][0]) == T
+
+
+def test_free_running_rollout_stays_close(uavtrack):
+    """200 free-running steps (no re-injection): fp32 drift stays small and the coverage
+    trace matches the fp64 oracle except on rare knife-edge steps."""
+    B, N, M, T = 64, 20, 10, 200
+    cfg = uavtrack.EnvConfig(n_envs=B, n_uav=N, m_targets=M)
+    env = uavtrack.BatchedUavEnv(cfg); env.reset(seed=11)
+    orc = OracleEnv(OracleConfig(n_envs=B, n_uav=N, m_targets=M), n_threads=8)
+    inject(orc, host(env.get_state()))
+    act = np.random.RandomState(2).randint(0, 12, size=(T, B, N)).astype(np.int32)
+    out = env.step_many(torch.from_numpy(act).cuda())
+    cov = out["covered"].cpu().numpy(); rew = out["reward"].cpu().numpy()
+    mism, rerr = 0, 0.0
+    for t in range(T):
+        ref = orc.step(act[t])
+        mism += int((cov[t] != ref["covered"]).sum())
+        rerr = max(rerr, np.median(np.abs(rew[t] - ref["reward"])))
+    st, rs = host(env.get_state()), orc.get_state()
+    assert np.abs(st["ux"] - rs["ux"]).max() < 5e-2 and np.abs(st["uy"] - rs["uy"]).max() < 5e-2
+    assert mism <= 0.002 * T * B, mism
+    assert rerr < 1e-5
+
+
+def test_full_size_properties_and_shard_equivalence(uavtrack):
+    """BASELINE configs[1] size (4096 x 20 x 10): invariants that need no oracle, and the
+    multi-GPU contract -- a shard [off, off+cnt) reproduces the unsharded batch bit for bit."""
+    B, N, M, T = 4096, 20, 10, 20
+    cfg = uavtrack.EnvConfig(n_envs=B, n_uav=N, m_targets=M, cooperative=0.3)
+    full = uavtrack.BatchedUavEnv(cfg); full.reset(seed=42)
+    act = torch.randint(0, 12, (T, B, N), dtype=torch.int32, device="cuda", generator=torch.Generator("cuda").manual_seed(42))
+    out = full.step_many(act)
+    assert torch.isfinite(out["obs"]).all() and torch.isfinite(out["reward"]).all()
+    assert out["reward"].abs().max() <= 1.0
+    t = out["terms"]
+    assert t[:, 0].min() >= 0 and t[:, 0].max() <= 1 and t[:, 1].min() >= -1 and t[:, 1].max() <= 0
+    assert t[:, 2].min() >= -1 and t[:, 2].max() <= 0
+    assert out["covered"].min() >= 0 and out["covered"].max() <= M
+    assert torch.equal(out["obs"][..., 11] * 12, act.float())          # a / Na carries the action index
+    from uavtrack.sharding import shard_range
+    for rank in (0, 3, 7):
+        off, cnt = shard_range(B, rank, 8)
+        sh = uavtrack.BatchedUavEnv(cfg.with_(n_envs=cnt, env_offset=off)); sh.reset(seed=42)
+        o2 = sh.step_many(act[:, off:off + cnt].contiguous())
+        for k in ("obs", "reward", "terms", "covered"):
+            sl = out[k][:, :, off:off + cnt] if k == "terms" else out[k][:, off:off + cnt]
+            assert torch.equal(o2[k], sl), (rank, k)
+        assert torch.equal(o2["ep_sums"], out["ep_sums"][off:off + cnt])
+
+
+def test_compat_environment_reference_call_shapes(uavtrack):
+    """The reference-shaped adapter (B = 1) driven exactly like train.operate_epoch."""
+    import random
+    ref_cfg = {"environment": {"n_uav": 5, "m_targets": 3, "x_max": 2000, "y_max": 2000, "na": 12},
+               "uav": {"dt": 1, "v_max": 20, "h_max": 6, "dc": 500, "dp": 200, "alpha": 0.6, "beta": 0.2, "gamma": 0.2},
+               "target": {"v_max": 5, "h_max": 6}, "cooperative": 0}
+    z, _ = load_golden("g1_n5m3_raw")
+    env = uavtrack.Environment(n_uav=5, m_targets=3, x_max=2000, y_max=2000, na=12)
+    random.seed(42)
+    assert env.reset(config=ref_cfg) is None
+    s0 = [u.get_local_state() for u in env.uav_list]
+    assert len(s0) == 5 and s0[0].shape == (12,) and np.all(s0[0][:9] == -1)
+    # put the adapter on the golden's initial state, then replay the golden's actions
+    env._env.set_state(**{k: z[k][0, 0][None] for k in ("ux", "uy", "uh", "ua", "tx", "ty", "th")})
+    for t in range(10):
+        nxt, reward, covered = env.step(ref_cfg, None, [int(a) for a in z["actions"][0, t]])
+        assert isinstance(covered, int) and set(reward) == {"rewards", "target_tracking_reward",
+                                                            "boundary_punishment", "duplicate_tracking_punishment"}
+        assert len(nxt) == 5 and all(len(v) == 5 for v in reward.values())
+        np.testing.assert_allclose(np.array(nxt), z["obs"][0, t], rtol=0, atol=1e-4)   # free-running fp32
+        np.testing.assert_allclose(reward["rewards"], z["reward"][0, t], rtol=0, atol=1e-4)
+        assert covered == int(z["covered"][0, t])
+    assert len(env.covered_target_num) == 10 and len(env.position["all_uav_xs"]) == 10
+    assert abs(env.uav_list[0].x - z["ux"][0, 10, 0]) < 1e-2

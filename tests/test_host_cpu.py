@@ -1,0 +1,129 @@
+"""CPU-only checks of the host layer and of the C-ABI boundary: the library loads,
+exports every symbol include/uavtrack.h declares, and fails loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+import uavtrack
+from uavtrack import _lib
+from uavtrack.config import EnvConfig, RewardMode
+from uavtrack.pmi import fold_pmi_state_dict, pmi_blob_size
+from uavtrack.sharding import shard_range
+
+
+def _have_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+def test_header_symbols_all_exported():
+    hdr = open(os.path.join(ROOT, "include", "uavtrack.h")).read()
+    declared = set(re.findall(r"\b(uavtrack_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.uavtrack_version() == _lib.ABI_VERSION
+
+
+def test_config_struct_matches_header_layout():
+    # 12 int32/uint32 (48 B) + int64 + 14 doubles; no implicit padding surprises
+    assert C.sizeof(_lib.UavtrackConfig) == 48 + 8 + 14 * 8
+    c = EnvConfig(n_envs=3, n_uav=20, m_targets=10, cooperative=0.3).c_struct(0)
+    assert c.struct_size == C.sizeof(_lib.UavtrackConfig)
+    assert (c.n_envs, c.n_uav, c.m_targets, c.reward_mode) == (3, 20, 10, int(RewardMode.MEAN))
+    assert c.norm_n_uav == 20 and c.norm_m_targets == 10
+
+
+def test_create_rejects_bad_config_with_message():
+    lib = _lib.load()
+    bad = EnvConfig(n_envs=0).c_struct(0)
+    h = C.c_void_p()
+    assert lib.uavtrack_create(C.byref(bad), C.byref(h)) != 0
+    assert b"n_envs" in lib.uavtrack_last_error()
+    bad = EnvConfig(n_envs=1, dim=2, nc=3).c_struct(0)
+    assert lib.uavtrack_create(C.byref(bad), C.byref(h)) != 0
+    assert b"nc must be 1" in lib.uavtrack_last_error()
+    bad = EnvConfig().c_struct(0)
+    bad.struct_size = 8
+    assert lib.uavtrack_create(C.byref(bad), C.byref(h)) != 0
+    assert b"ABI mismatch" in lib.uavtrack_last_error()
+
+
+@pytest.mark.skipif(_have_gpu(), reason="checks the no-GPU failure mode")
+def test_no_cpu_fallback_fails_loudly():
+    lib = _lib.load()
+    ok = EnvConfig(n_envs=4).c_struct(0)
+    h = C.c_void_p()
+    assert lib.uavtrack_create(C.byref(ok), C.byref(h)) != 0
+    assert b"no CPU fallback" in lib.uavtrack_last_error()
+    with pytest.raises(RuntimeError):
+        uavtrack.BatchedUavEnv(EnvConfig(n_envs=4), "cpu")
+    with pytest.raises(RuntimeError, match="no CPU fallback|no HIP device"):
+        uavtrack.BatchedUavEnv(EnvConfig(n_envs=4), "cuda:0")
+
+
+def test_null_handle_calls_return_errors():
+    lib = _lib.load()
+    assert lib.uavtrack_step(None, None, None, None, None, None, None, None) != 0
+    assert b"null handle" in lib.uavtrack_last_error()
+    assert lib.uavtrack_destroy(None) == 0
+
+
+def test_reference_dict_adapter():
+    ref_cfg = {"environment": {"n_uav": 10, "m_targets": 10, "x_max": 2000, "y_max": 2000, "na": 12},
+               "uav": {"dt": 1, "v_max": 20, "h_max": 6, "dc": 500, "dp": 200, "alpha": 0.6, "beta": 0.2, "gamma": 0.2},
+               "target": {"v_max": 5, "h_max": 6}, "cooperative": 0.3}
+    c = EnvConfig.from_reference_dict(ref_cfg, n_envs=7)
+    assert c == EnvConfig(n_envs=7, cooperative=0.3)
+    assert abs(c.u_h_max - np.pi / 6) < 1e-15 and c.resolved_mode() == RewardMode.MEAN
+    assert EnvConfig().resolved_mode() == RewardMode.RAW
+
+
+def test_pmi_fold_equals_unfolded_eval_forward(pmi_state_dict):
+    sd = pmi_state_dict
+    blob, H = fold_pmi_state_dict(sd)
+    assert H == 128 and blob.size == pmi_blob_size(128) and blob.dtype == np.float32
+    rng = np.random.RandomState(0)
+    x = rng.randn(16, 12)
+
+    def bn(v, p):
+        return (v - sd[p + ".running_mean"]) / np.sqrt(sd[p + ".running_var"] + 1e-5) * sd[p + ".weight"] + sd[p + ".bias"]
+    cat = np.concatenate([
+        np.maximum(bn(x[:, :5] @ sd["fc_comm.weight"].T + sd["fc_comm.bias"], "bn_comm"), 0),
+        np.maximum(bn(x[:, 5:9] @ sd["fc_obs.weight"].T + sd["fc_obs.bias"], "bn_obs"), 0),
+        np.maximum(bn(x[:, 9:] @ sd["fc_boundary_state.weight"].T + sd["fc_boundary_state.bias"], "bn_boundary_state"), 0)], 1)
+    hid = np.maximum(bn(cat @ sd["fc1.weight"].T + sd["fc1.bias"], "bn1"), 0)
+    want = hid @ sd["fc2.weight"].T + sd["fc2.bias"]
+
+    b = blob.astype(np.float64)
+    o = 0
+    def take(n, shape):
+        nonlocal o
+        v = b[o:o + n].reshape(shape); o += n
+        return v
+    wc, bc = take(5 * H, (5, H)), take(H, (H,))
+    wo, bo = take(4 * H, (4, H)), take(H, (H,))
+    wb, bb = take(3 * H, (3, H)), take(H, (H,))
+    w1, b1 = take(3 * H * H, (3 * H, H)), take(H, (H,))
+    w2, b2 = take(H, (H,)), take(1, (1,))
+    cat2 = np.concatenate([np.maximum(x[:, :5] @ wc + bc, 0), np.maximum(x[:, 5:9] @ wo + bo, 0),
+                           np.maximum(x[:, 9:] @ wb + bb, 0)], 1)
+    got = np.maximum(cat2 @ w1 + b1, 0) @ w2 + b2
+    np.testing.assert_allclose(got, want[:, 0], rtol=0, atol=2e-5)
+
+
+def test_shard_range_partitions_exactly():
+    for total in (1, 7, 8, 4096, 32768, 1000):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+            for (o0, c0), (o1, _) in zip(spans, spans[1:]):
+                assert o0 + c0 == o1
+    with pytest.raises(ValueError):
+        shard_range(8, 8, 8)
