@@ -1,0 +1,287 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the environment hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one Environment.step over the whole batch (every env advances once).
+At N = 1 the workload is BASELINE.json configs[1]: 4096 envs x 20 UAVs x 10 targets,
+2-D, MAAC tracking reward; for N > 1 every rank runs that same batch on its own GPU
+(weak scaling, configs[4]) and the only collective is the end-of-rollout all-gather of
+the per-env episode accumulators over RCCL.
+
+Timed region: K steps issued as fused rollouts of `--rollout` (default 200 = the
+reference horizon, main.py:128) steps per launch with pre-sampled int32 actions resident
+in HBM, a reset between rollouts, bracketed by barrier + synchronize, max
+over ranks.  Rank 0 prints ONE JSON line.  Extra keys on that line:
+  roofline      dominant kernel (rollout_kernel) vs the 8 TB/s HBM roof, algorithmic bytes
+  cpu_baseline  the C oracle (a port of the reference algorithm) timed on this host's cores
+  per_step_launch / saturating_batch   the same kernel launched one step at a time, and at a
+                batch large enough to fill the chip
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "marl-uavs-targets-tracking_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_COPY_CEILING_GBS = 6290.0
+
+
+def algorithmic_bytes_per_agent_step(n_uav, m_targets, dim=2, terms=True):
+    """read UAV x,y,h,a_prev + action 20, write UAV state 16, obs 48, reward 4,
+    3 reward terms 12, targets r+w 24*M/N, covered+done 5/N  (3-D: +8 and 32*M/N)."""
+    b = 20 + 16 + 48 + 4 + (12 if terms else 0) + 5.0 / n_uav
+    if dim == 3:
+        return b + 8 + 32.0 * m_targets / n_uav
+    return b + 24.0 * m_targets / n_uav
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=400)
+    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--n-uav", type=int, default=20)
+    ap.add_argument("--m-targets", type=int, default=10)
+    ap.add_argument("--dim", type=int, default=2)
+    ap.add_argument("--cooperative", type=float, default=0.0)
+    ap.add_argument("--rollout", type=int, default=200, help="steps per fused launch (1 = one launch per step)")
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip per-step-launch and saturating-batch legs")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def make_env(uavtrack, args, B, device, env_offset=0):
+    nc = 3 if args.dim == 3 else 1
+    cfg = uavtrack.EnvConfig(n_envs=B, n_uav=args.n_uav, m_targets=args.m_targets, dim=args.dim, nc=nc,
+                             cooperative=args.cooperative, horizon=args.rollout if args.rollout > 1 else 200,
+                             env_offset=env_offset)
+    return uavtrack.BatchedUavEnv(cfg, device)
+
+
+def run_rollouts(env, actions, steps, rollout, out, events=None, gather=None):
+    """Issue `steps` env steps as ceil(steps / rollout) launches; returns #launches."""
+    import torch
+    done_steps, launches, ep_steps = 0, 0, 0
+    horizon = env.cfg.horizon
+    while done_steps < steps:
+        T = min(rollout, steps - done_steps)
+        if events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        res = env.step_many(actions[:T], out=out.get(T))
+        if events is not None:
+            e1.record()
+            events.append((e0, e1, T))
+        out[T] = res
+        done_steps += T
+        launches += 1
+        ep_steps += T
+        if ep_steps >= horizon:               # end of an episode: gather summaries, start the next one
+            if gather is not None:
+                gather(res["ep_sums"])
+            env.reset(seed=42)
+            ep_steps = 0
+    return launches
+
+
+def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, env_offset=0, total_envs=None):
+    import torch
+    env = make_env(uavtrack, args, B, device, env_offset)
+    na_total = env.cfg.na_total
+    g = torch.Generator(device=device).manual_seed(args.seed + env_offset)
+    actions = torch.randint(0, na_total, (rollout, B, args.n_uav), dtype=torch.int32, device=device, generator=g)
+    out = {}
+    gather = None
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        gather = lambda ep: uavtrack.gather_rollout_summary(ep, n_envs_total=total_envs)
+    env.reset(seed=args.seed)
+    run_rollouts(env, actions, warmup, rollout, out, gather=gather)
+    torch.cuda.synchronize(device)
+    if gather is not None:
+        dist.barrier()
+    events = []
+    t0 = time.perf_counter()
+    launches = run_rollouts(env, actions, steps, rollout, out, events=events, gather=gather)
+    torch.cuda.synchronize(device)
+    if gather is not None:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    kern_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in events)
+    info = env.kernel_info()
+    env.close()
+    return dict(wall_s=wall, kernel_ms_total=kern_ms, launches=launches, steps=steps, geometry=info)
+
+
+def host_cores():
+    """CPUs this process may really use: the cgroup quota when there is one (the GPU box
+    grants 16 of the host's 256), else the affinity mask."""
+    if "UAVTRACK_CPU_THREADS" in os.environ:
+        return int(os.environ["UAVTRACK_CPU_THREADS"])
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(args, seconds):
+    """The C oracle (oracle/uav_oracle.c: scalar fp64 port of the reference algorithm) on this
+    host's cores, on a bounded sample of the same workload.  Reported, never the target."""
+    import numpy as np
+    from oracle import OracleConfig, OracleEnv
+    # the GPU box gives one GPU's share of the host: 16 cores (os.cpu_count() reports the whole machine)
+    cores = host_cores()
+    N, M = args.n_uav, args.m_targets
+
+    def run(B, T, threads):
+        env = OracleEnv(OracleConfig(n_envs=B, n_uav=N, m_targets=M, cooperative=args.cooperative,
+                                     dim=2), n_threads=threads)
+        env.reset_philox(seed=args.seed)
+        act = np.random.RandomState(args.seed).randint(0, 12, size=(T, B, N)).astype(np.int32)
+        t0 = time.perf_counter()
+        for t in range(T):
+            env.step(act[t])
+        return B * N * T / (time.perf_counter() - t0)
+
+    r1 = run(64, 20, 1)                                      # calibrate
+    rN = run(64 * cores, 20, cores)
+    T = 200
+    B = int(max(cores, min(4096, rN * seconds * 0.7 / (N * T))))
+    B1 = int(max(1, min(4096, r1 * seconds * 0.3 / (N * T))))
+    vN = run(B, T, cores)
+    v1 = run(B1, T, 1)
+    return dict(value=vN, unit="agent-steps/s", cores=cores, kind="port",
+                sample=f"{B} envs x {N} UAVs x {M} targets x {T} steps, fp64 scalar C oracle, {cores} OpenMP threads",
+                value_1core=v1, sample_1core=f"{B1} envs x {T} steps, 1 thread")
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import uavtrack
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the environment has no CPU path")
+    device = f"cuda:{local_rank}"
+    torch.cuda.set_device(device)
+
+    B, N, M = args.envs, args.n_uav, args.m_targets
+    res = time_config(uavtrack, args, B, args.steps, args.warmup, args.rollout, device,
+                      dist=dist if world > 1 else None, env_offset=rank * B, total_envs=world * B)
+    wall = torch.tensor([res["wall_s"]], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+    wall_s = float(wall.item())
+
+    if rank == 0:
+        bytes_unit = algorithmic_bytes_per_agent_step(N, M, args.dim)
+        agent_steps = world * B * N * args.steps
+        value = agent_steps / wall_s
+        units_per_launch = B * N * args.rollout
+        avg_launch_ms = res["kernel_ms_total"] / res["launches"]
+        avg_units = B * N * args.steps / res["launches"]
+        achieved = bytes_unit * avg_units / (avg_launch_ms * 1e-3) / 1e9
+        line = {
+            "metric": "env agent-steps/sec",
+            "value": value,
+            "unit": "agent-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall_s * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{B} envs x {N} UAVs x {M} targets per GPU, {args.dim}-D, "
+                            f"{'MAAC tracking reward' if args.cooperative == 0 else 'MAAC-G neighbour-mean reward'}"
+                            f" (BASELINE configs[{1 if world == 1 else 4}])",
+                "envs_total": world * B,
+                "launch": f"uavtrack_step_many, {args.rollout} steps per launch, reset between rollouts"
+                          if args.rollout > 1 else "uavtrack_step, one launch per step",
+                "actions": "pre-sampled int32[T,B,N] uniform, seed 42, resident in HBM",
+                "outputs": "obs[T,B,N,12] reward[T,B,N] terms[T,3,B,N] covered[T,B] done[T,B] ep_sums[B,5], all written",
+                "parallelism": f"env-sharded x{world}, RCCL all-gather of ep_sums per rollout" if world > 1 else "1 GPU",
+                "geometry": res["geometry"],
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "rollout_kernel",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_agent_step": bytes_unit,
+                "agent_steps_per_launch": avg_units,
+                "avg_launch_ms": avg_launch_ms,
+                "launches_timed": res["launches"],
+                "timing": "HIP events on the launch stream, around every rollout launch of the timed region",
+            },
+        }
+        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(traffic_file):
+            try:
+                tr = json.load(open(traffic_file))
+                key = f"{B}x{N}x{M}_T{args.rollout}"
+                if key in tr:
+                    line["roofline"]["traffic"] = tr[key]["hbm_bytes_per_launch"]
+                    line["roofline"]["traffic_source"] = tr[key].get("source", "profiles/")
+            except Exception:
+                pass
+        if world == 1 and not args.no_extras:
+            # the same kernel, one launch per env step (what a closed-loop policy would do eagerly)
+            k = min(args.steps, 1000)
+            r1 = time_config(uavtrack, args, B, k, min(args.warmup, 200), 1, device)
+            line["per_step_launch"] = {
+                "agent_steps_per_s": B * N * k / r1["wall_s"], "ms_per_step": r1["wall_s"] * 1e3 / k,
+                "kernel_ms_per_step": r1["kernel_ms_total"] / r1["launches"],
+                "note": "uavtrack_step eager from Python/ctypes; host-launch bound",
+            }
+            # a batch that fills the chip (SURVEY 8d 'bandwidth-saturating batch')
+            Bs, Ts, Ks = 65536, 50, 200
+            rs = time_config(uavtrack, args, Bs, Ks, Ts, Ts, device)
+            ach = bytes_unit * (Bs * N * Ks / rs["launches"]) / (rs["kernel_ms_total"] / rs["launches"] * 1e-3) / 1e9
+            line["saturating_batch"] = {
+                "workload": f"{Bs} envs x {N} UAVs x {M} targets, {Ts} steps per launch",
+                "agent_steps_per_s": Bs * N * Ks / rs["wall_s"],
+                "roofline_achieved_GBs": ach, "roofline_frac": ach / HBM_PEAK_GBS,
+                "avg_launch_ms": rs["kernel_ms_total"] / rs["launches"], "geometry": rs["geometry"],
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+            line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

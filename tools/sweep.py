@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""A/B timing helper (GPU box): times uavtrack_step_many for one config under several
+workgroup sizes / library builds.  usage: sweep.py [--lib path.so] [--envs B] [--T T] [--wgs 64,128,...]"""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "marl-uavs-targets-tracking_amd")]
+ap = argparse.ArgumentParser()
+ap.add_argument("--lib"); ap.add_argument("--envs", type=int, default=4096); ap.add_argument("--T", type=int, default=200)
+ap.add_argument("--n", type=int, default=20); ap.add_argument("--m", type=int, default=10)
+ap.add_argument("--coop", type=float, default=0.0); ap.add_argument("--wgs", default="0")
+ap.add_argument("--reps", type=int, default=5); ap.add_argument("--dim", type=int, default=2)
+a = ap.parse_args()
+import torch
+import uavtrack
+from uavtrack import _lib
+if a.lib:
+    _lib.LIB_PATH = os.path.abspath(a.lib)
+for wgs in [int(w) for w in a.wgs.split(",")]:
+    if wgs: os.environ["UAVTRACK_WGS"] = str(wgs)
+    else: os.environ.pop("UAVTRACK_WGS", None)
+    cfg = uavtrack.EnvConfig(n_envs=a.envs, n_uav=a.n, m_targets=a.m, cooperative=a.coop, dim=a.dim, nc=3 if a.dim == 3 else 1)
+    env = uavtrack.BatchedUavEnv(cfg)
+    env.reset(seed=1)
+    act = torch.randint(0, cfg.na_total, (a.T, a.envs, a.n), dtype=torch.int32, device="cuda")
+    out = env.step_many(act)
+    torch.cuda.synchronize()
+    best = []
+    for r in range(a.reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); out = env.step_many(act, out=out); e1.record(); torch.cuda.synchronize()
+        best.append(e0.elapsed_time(e1))
+    ms = sorted(best)[len(best) // 2]
+    rate = a.envs * a.n * a.T / (ms * 1e-3)
+    print(f"lib={os.path.basename(a.lib or 'default')} B={a.envs} N={a.n} M={a.m} T={a.T} wgs={env.kernel_info()['workgroup']} "
+          f"median {ms:.3f} ms  min {min(best):.3f} ms  {rate/1e9:.2f} G agent-steps/s", flush=True)
+    env.close()
