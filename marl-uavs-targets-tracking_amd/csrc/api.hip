@@ -42,9 +42,9 @@ hipError_t dmalloc(T **p, size_t n)
 
 void free_state(uavtrack_env *env)
 {
-    StepParams &s = env->base;
+    StateBlock &s = env->state;
     void *ptrs[] = {s.ux, s.uy, s.uz, s.uh, s.ua, s.tx, s.ty, s.tz, s.th, s.step_count,
-                    env->pmi.blob, env->pmi_scratch};
+                    env->d_state, env->pmi.blob, env->pmi_scratch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -69,7 +69,7 @@ int validate(const uavtrack_config &c)
     return 0;
 }
 
-void fold_constants(const uavtrack_config &c, StepParams &p)
+void fold_constants(const uavtrack_config &c, StepParams &p, StateBlock &sb)
 {
     p.B = c.n_envs; p.N = c.n_uav; p.M = c.m_targets;
     p.na = c.na; p.na_total = c.na * c.nc; p.horizon = c.horizon;
@@ -98,8 +98,8 @@ void fold_constants(const uavtrack_config &c, StepParams &p)
     for (int k = 0; k < UAVTRACK_MAX_CLIMB; ++k) {
         double g = 0.0;
         if (c.nc > 1 && k < c.nc) g = (2.0 * k - (c.nc - 1)) * c.u_g_max / (double)(c.nc - 1);
-        p.climb_c[k] = (float)std::cos(g);
-        p.climb_s[k] = (float)std::sin(g);
+        sb.climb_c[k] = (float)std::cos(g);
+        sb.climb_s[k] = (float)std::sin(g);
     }
 }
 
@@ -135,7 +135,8 @@ int uavtrack_create(const uavtrack_config *cfg, uavtrack_env **out)
     if (!env) return fail("uavtrack_create: out of host memory");
     env->cfg = *cfg;
     memset(&env->base, 0, sizeof env->base);
-    fold_constants(*cfg, env->base);
+    memset(&env->state, 0, sizeof env->state);
+    fold_constants(*cfg, env->base, env->state);
     env->geo = plan_geometry(*cfg);
     if (env->geo.wgs == 0) {
         delete env;
@@ -149,7 +150,7 @@ int uavtrack_create(const uavtrack_config *cfg, uavtrack_env **out)
                     cfg->m_targets);
     }
 
-    StepParams &s = env->base;
+    StateBlock &s = env->state;
     const size_t BN = (size_t)cfg->n_envs * cfg->n_uav, BM = (size_t)cfg->n_envs * cfg->m_targets;
     hipError_t err = hipSuccess;
     auto keep = [&](hipError_t r) { if (err == hipSuccess) err = r; };
@@ -164,6 +165,9 @@ int uavtrack_create(const uavtrack_config *cfg, uavtrack_env **out)
         keep(hipMemset(s.th, 0, (BM ? BM : 1) * 4));
         keep(hipMemset(s.step_count, 0, (size_t)cfg->n_envs * 4));
         if (cfg->dim == 3) { keep(hipMemset(s.uz, 0, BN * 4)); keep(hipMemset(s.tz, 0, (BM ? BM : 1) * 4)); }
+        keep(dmalloc(&env->d_state, 1));
+        if (err == hipSuccess) keep(hipMemcpy(env->d_state, &env->state, sizeof(StateBlock), hipMemcpyHostToDevice));
+        env->base.st = env->d_state;
     }
     if (err != hipSuccess) {
         free_state(env);
@@ -202,7 +206,7 @@ int uavtrack_set_state(uavtrack_env *env, const float *ux, const float *uy, cons
     if (c.dim == 3 && (!uz || (c.m_targets > 0 && !tz))) return fail("uavtrack_set_state: dim == 3 needs uz and tz");
     HIP_TRY(hipSetDevice(c.device_id));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    StepParams &s = env->base;
+    StateBlock &s = env->state;
     const size_t BN = (size_t)c.n_envs * c.n_uav * 4, BM = (size_t)c.n_envs * c.m_targets * 4;
     HIP_TRY(hipMemcpyAsync(s.ux, ux, BN, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(s.uy, uy, BN, hipMemcpyDeviceToDevice, st));
@@ -231,7 +235,7 @@ int uavtrack_get_state(uavtrack_env *env, float *ux, float *uy, float *uz, float
     const uavtrack_config &c = env->cfg;
     HIP_TRY(hipSetDevice(c.device_id));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    StepParams &s = env->base;
+    StateBlock &s = env->state;
     const size_t BN = (size_t)c.n_envs * c.n_uav * 4, BM = (size_t)c.n_envs * c.m_targets * 4;
     if (ux) HIP_TRY(hipMemcpyAsync(ux, s.ux, BN, hipMemcpyDeviceToDevice, st));
     if (uy) HIP_TRY(hipMemcpyAsync(uy, s.uy, BN, hipMemcpyDeviceToDevice, st));

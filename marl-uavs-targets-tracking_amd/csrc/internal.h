@@ -15,12 +15,19 @@ constexpr int kMaxWorkgroup = 512;   // __launch_bounds__ of the rollout kernel
 
 // Kernel arguments of one rollout launch (T >= 1 steps).  All pointers are device
 // pointers.  Derived constants are computed once on the host in fp64, then cast.
-struct StepParams {
+// Per-handle block that lives in device memory: the kernel reaches the state arrays through
+// one pointer instead of carrying 10 pointers (20 SGPRs) through the whole step loop.
+struct StateBlock {
     // state, SoA over (env, uav) and (env, target); updated in place
     float *ux, *uy, *uz, *uh;
     int32_t *ua;
     float *tx, *ty, *tz, *th;
     int32_t *step_count;
+    float climb_c[UAVTRACK_MAX_CLIMB], climb_s[UAVTRACK_MAX_CLIMB];   // cos/sin of the climb angles
+};
+
+struct StepParams {
+    const StateBlock *st;
     // per-step I/O, leading [T] axis
     const int32_t *actions;
     float *obs, *reward, *terms, *raw_out;
@@ -40,7 +47,6 @@ struct StepParams {
     float tt_ceil, inv_tt_ceil;  // 2*m_targets                   (environment.py:208)
     float dup_floor, inv_dup;    // -e/2*n_uav and 1/(e/2*n_uav)  (environment.py:210)
     float alpha, beta, gamma, coop;
-    float climb_c[UAVTRACK_MAX_CLIMB], climb_s[UAVTRACK_MAX_CLIMB];   // cos/sin of the climb angles
 };
 
 struct PmiWeights {
@@ -61,7 +67,9 @@ struct Geometry {
 
 struct uavtrack_env {
     uavtrack_config cfg;
-    uavtrack::StepParams base;   // constants + state pointers filled at create
+    uavtrack::StepParams base;   // constants filled at create
+    uavtrack::StateBlock state;  // host copy of the device-resident block
+    uavtrack::StateBlock *d_state = nullptr;
     uavtrack::Geometry geo;
     uavtrack::PmiWeights pmi;
     // PMI scratch (allocated on first use)

@@ -66,19 +66,20 @@ hipError_t launch_reset(const uavtrack_env *env, uint64_t seed, uint32_t episode
                         hipStream_t stream)
 {
     const uavtrack_config &c = env->cfg;
-    const StepParams &s = env->base;
+    const StateBlock &s = env->state;
+    const StepParams &k = env->base;
     ResetParams p;
     p.ux = s.ux; p.uy = s.uy; p.uz = s.uz; p.uh = s.uh; p.ua = s.ua;
     p.tx = s.tx; p.ty = s.ty; p.tz = s.tz; p.th = s.th;
     p.step_count = s.step_count;
     p.obs = obs;
     p.B = c.n_envs; p.N = c.n_uav; p.M = c.m_targets; p.dim = c.dim;
-    p.na_total = s.na_total;
+    p.na_total = k.na_total;
     p.env_offset = c.env_offset;
     p.k0 = (uint32_t)seed; p.k1 = (uint32_t)(seed >> 32); p.episode = episode;
     p.x_max = c.x_max; p.y_max = c.y_max; p.z_max = c.z_max;
     p.x_max_f = (float)c.x_max; p.y_max_f = (float)c.y_max; p.z_max_f = (float)c.z_max;
-    p.inv_dc = s.inv_dc; p.inv_na_total = s.inv_na_total;
+    p.inv_dc = k.inv_dc; p.inv_na_total = k.inv_na_total;
     const long long total = (long long)c.n_envs * (c.n_uav + c.m_targets);
     const int threads = 256;
     const unsigned blocks = (unsigned)((total + threads - 1) / threads);

@@ -34,10 +34,10 @@
 // Partial unrolling of the pair sweeps: full unrolling lets the scheduler hoist every
 // LDS table read of the environment into registers (256 VGPRs + scratch spills).
 #ifndef UAVTRACK_UNROLL_U
-#define UAVTRACK_UNROLL_U 4
+#define UAVTRACK_UNROLL_U 5
 #endif
 #ifndef UAVTRACK_UNROLL_T
-#define UAVTRACK_UNROLL_T 2
+#define UAVTRACK_UNROLL_T 5
 #endif
 
 namespace uavtrack {
@@ -88,47 +88,73 @@ __device__ __forceinline__ float wrap_heading(float h)
     return h;
 }
 
-// The two pair sweeps of one UAV.  WEIGHTED is the literal uav.py:165/179 weight
-// min(dist((rel_x, rel_y), (abs_x, abs_y)), 1): it differs from 1 only when the
-// UAV sits within ~2.5 m of the origin, so the fast path drops it.
-template <int N_, int M_, bool Z3, bool WEIGHTED>
-__device__ __forceinline__ void sweep(const StepParams &p, int N, int M, int ebaseU, int ebaseT, int i, int pn,
-                                      const float4 *__restrict__ utab, const float *__restrict__ atab,
-                                      const float *__restrict__ uzt, const float4 *__restrict__ ttab,
-                                      const float *__restrict__ tzt, unsigned *__restrict__ covw, int covbase,
-                                      float xi, float yi, float zi, float ci, float si, float ai, Acc &a)
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+// sin/cos for |h| <= pi (headings are kept wrapped): quadrant reduction with a two-term
+// pi/2 and the Cephes single-precision minimax polynomials on [-pi/4, pi/4] (|err| ~ 1e-7).
+// ocml's sincosf carries a large-argument (Payne-Hanek) path the kernel never needs inside
+// the step loop; it is only used for injected state whose heading is out of range.
+__device__ __forceinline__ void sincos_wrapped(float h, float *s, float *c)
 {
-    a = Acc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const float q = rintf(h * 0.63661977236758134308f);
+    float r = fmaf(-q, 1.57079637050628662109375f, h);       // fl32(pi/2); q in {-2..2}: q * hi is exact
+    r = fmaf(-q, -4.371139006309477e-08f, r);                // pi/2 - fl32(pi/2)
+    const float z = r * r;
+    const float sp = fmaf(r * z, fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+    const float cp = fmaf(z * z, fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+                          fmaf(z, -0.5f, 1.0f));
+    const int qi = (int)q;
+    const float ss = (qi & 1) ? cp : sp;
+    const float cc = (qi & 1) ? sp : cp;
+    *s = (qi & 2) ? -ss : ss;
+    *c = ((qi + 1) & 2) ? -cc : cc;
+}
+
+__device__ __forceinline__ void sincos_any(float h, float *s, float *c)
+{
+    if (__builtin_expect(fabsf(h) <= kPi, 1)) sincos_wrapped(h, s, c);
+    else sincosf(h, s, c);
+}
+
+// ---------------------------------------------------------------------------------------
+// Pair sweeps of one UAV, fast path: packed fp32 (v_pk_*) on (x, y) / (cos, sin) pairs,
+// no per-pair `j != i` test.  The j == i iteration adds a known self term (distance 0 on
+// the post-move table, own pre-move pose on the sequential table); the accumulators start
+// at minus that term.  The uav.py:165/179 weight is 1 here (see sweep_weighted).
+template <int N_, int M_, bool Z3>
+__device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, int ebaseT, int i,
+                                           const float4 *__restrict__ rowNew, const float4 *__restrict__ rowOld,
+                                           const float4 *__restrict__ ttab,
+                                           const float *__restrict__ tzt, unsigned *__restrict__ covw, int covbase,
+                                           float xi, float yi, float zi, float ci, float si, float ai,
+                                           float xo, float yo, float zo, float co, float so, float ao, Acc &a)
+{
+    const v2f pos = {xi, yi};
 
     // ---- targets: observe_target (<= dp), tracking reward (<= dp), coverage (< dp)
+    v2f sxyT = {0.f, 0.f}, scsT = {0.f, 0.f};
+    float cntT = 0.f, trk = 0.f;
     unsigned bits = 0;
 #pragma unroll UAVTRACK_UNROLL_T
     for (int k = 0; k < (M_ > 0 ? M_ : M); ++k) {
         const float4 tg = ttab[ebaseT + k];
-        const float dx = tg.x - xi, dy = tg.y - yi;
-        float d2 = dx * dx + dy * dy;
+        const v2f d = (v2f){tg.x, tg.y} - pos;
+        const v2f sq = d * d;
+        float d2 = sq.x + sq.y;
         if (Z3) {
             const float dz = tzt[ebaseT + k] - zi;
-            d2 += dz * dz;
+            d2 = fmaf(dz, dz, d2);
         }
-        const float d = fast_sqrt(d2);
+        const float dist = fast_sqrt(d2);
         const bool in = d2 <= p.dp2;
         const float m = in ? 1.0f : 0.0f;
-        float iw = m;
-        if (WEIGHTED) {
-            const float rx = dx * p.inv_dp - xi, ry = dy * p.inv_dp - yi;
-            iw = in ? 1.0f / fminf(sqrtf(rx * rx + ry * ry), 1.0f) : 0.0f;
-            a.scT = fmaf(iw, tg.z * p.vratio - ci, a.scT);
-            a.ssT = fmaf(iw, tg.w * p.vratio - si, a.ssT);
-        } else {
-            a.scT = fmaf(m, tg.z, a.scT);
-            a.ssT = fmaf(m, tg.w, a.ssT);
-        }
-        a.cntT += m;
-        a.iwT += iw;
-        a.sxT = fmaf(iw, dx, a.sxT);
-        a.syT = fmaf(iw, dy, a.syT);
-        a.trk += in ? fmaf(-d, p.inv_dp, 2.0f) : 0.0f;   // 1 + (dp - d)/dp
+        const v2f mm = {m, m};
+        sxyT = pk_fma(mm, d, sxyT);
+        scsT = pk_fma(mm, (v2f){tg.z, tg.w}, scsT);
+        cntT += m;
+        trk = fmaf(m, fmaf(-dist, p.inv_dp, 2.0f), trk);   // 1 + (dp - d)/dp
         bits |= (d2 < p.dp2) ? (1u << (k & 31)) : 0u;
         if ((k & 31) == 31 || k == (M_ > 0 ? M_ : M) - 1) {
             if (bits) atomicOr(&covw[covbase + (k >> 5)], bits);
@@ -136,56 +162,119 @@ __device__ __forceinline__ void sweep(const StepParams &p, int N, int M, int eba
         }
     }
 
-    // ---- peers: duplicate punishment on post-move poses (<= 2dp), observe_uav on
-    //      the sequential view (<= dc): j < i post-move, j > i pre-move
+    // ---- peers.  Self terms first.
+    const float dup_self = fast_exp2(p.exp_k0);            // exp2(k0 - k1 * 0), as the loop computes it
+    const v2f dself = (v2f){xo, yo} - pos;
+    const v2f sqs = dself * dself;
+    float d2self = sqs.x + sqs.y;
+    if (Z3) d2self = fmaf(zo - zi, zo - zi, d2self);
+    const float mself = (d2self <= p.dc2) ? 1.0f : 0.0f;   // own pre-move pose, seen at j == i
+    const v2f nself = {-mself, -mself};
+    v2f sxyU = nself * dself, scsU = nself * (v2f){co, so}, sacU = nself * (v2f){ao, 1.0f};
+    float dup = -dup_self;
 #pragma unroll UAVTRACK_UNROLL_U
     for (int j = 0; j < (N_ > 0 ? N_ : N); ++j) {
-        const int row = (ebaseU + j) * 2;
-        const bool other = (j != i);
-        const float4 nw = utab[row + pn];
-        const float dxn = nw.x - xi, dyn = nw.y - yi;
-        float d2n = dxn * dxn + dyn * dyn;
-        const int sel = (j < i) ? pn : (pn ^ 1);
-        const float4 mx = utab[row + sel];
-        const float am = atab[row + sel];
-        const float dxm = mx.x - xi, dym = mx.y - yi;
-        float d2m = dxm * dxm + dym * dym;
+        const float4 *rs = (j < i) ? rowNew : rowOld;       // one select serves pose, action and z
+        const float4 nw = rowNew[j * 4];
+        const float4 mx = rs[j * 4];
+        const float4 ax = rs[j * 4 + 1];                    // (action, 1, z, -)
+        const v2f am = {ax.x, ax.y};
+        const v2f dn = (v2f){nw.x, nw.y} - pos;
+        const v2f dm = (v2f){mx.x, mx.y} - pos;
+        const v2f sqn = dn * dn, sqm = dm * dm;
+        float d2n = sqn.x + sqn.y, d2m = sqm.x + sqm.y;
         if (Z3) {
-            const float dzn = uzt[row + pn] - zi;
-            const float dzm = uzt[row + sel] - zi;
-            d2n += dzn * dzn;
-            d2m += dzm * dzm;
+            const float dzn = rowNew[j * 4 + 1].z - zi, dzm = ax.z - zi;
+            d2n = fmaf(dzn, dzn, d2n);
+            d2m = fmaf(dzm, dzm, d2m);
         }
-        const float dn = fast_sqrt(d2n);
-        const float ex = fast_exp2(fmaf(dn, -p.exp_k1, p.exp_k0));
-        a.dup += (other && d2n <= p.two_dp2) ? ex : 0.0f;
+        const float ex = fast_exp2(fmaf(fast_sqrt(d2n), -p.exp_k1, p.exp_k0));
+        dup += (d2n <= p.two_dp2) ? ex : 0.0f;
+        const float m = (d2m <= p.dc2) ? 1.0f : 0.0f;
+        const v2f mm = {m, m};
+        sxyU = pk_fma(mm, dm, sxyU);
+        scsU = pk_fma(mm, (v2f){mx.z, mx.w}, scsU);
+        sacU = pk_fma(mm, am, sacU);
+    }
+    // sum_j m (c_j - c_i) = sum_j m c_j - c_i cnt; targets carry the speed ratio
+    a.cntT = cntT; a.iwT = cntT; a.sxT = sxyT.x; a.syT = sxyT.y; a.trk = trk;
+    a.scT = fmaf(scsT.x, p.vratio, -ci * cntT);
+    a.ssT = fmaf(scsT.y, p.vratio, -si * cntT);
+    a.cntU = sacU.y; a.iwU = sacU.y; a.sxU = sxyU.x; a.syU = sxyU.y; a.dup = dup;
+    a.scU = fmaf(-ci, sacU.y, scsU.x);
+    a.ssU = fmaf(-si, sacU.y, scsU.y);
+    a.saU = fmaf(-ai, sacU.y, sacU.x);
+}
 
+// Literal form with the uav.py:165/179 weight min(dist((rel_x, rel_y), (abs_x, abs_y)), 1).
+// It differs from 1 only when the UAV sits within ~2.5 m of the origin, so this path runs
+// for the few wavefronts that hold such a UAV and favours clarity over speed.
+template <int N_, int M_, bool Z3>
+__device__ __forceinline__ void sweep_weighted(const StepParams &p, int N, int M, int ebaseT, int i,
+                                            const float4 *__restrict__ rowNew, const float4 *__restrict__ rowOld,
+                                            const float4 *__restrict__ ttab,
+                                            const float *__restrict__ tzt, unsigned *__restrict__ covw, int covbase,
+                                            float xi, float yi, float zi, float ci, float si, float ai, Acc &a)
+{
+    a = Acc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned bits = 0;
+#pragma unroll 1
+    for (int k = 0; k < M; ++k) {
+        const float4 tg = ttab[ebaseT + k];
+        const float dx = tg.x - xi, dy = tg.y - yi;
+        const v2f sq = (v2f){dx, dy} * (v2f){dx, dy};        // same products as the fast path
+        float d2 = sq.x + sq.y;
+        if (Z3) {
+            const float dz = tzt[ebaseT + k] - zi;
+            d2 = fmaf(dz, dz, d2);
+        }
+        const float d = fast_sqrt(d2);
+        const bool in = d2 <= p.dp2;
+        const float m = in ? 1.0f : 0.0f;
+        const float rx = dx * p.inv_dp - xi, ry = dy * p.inv_dp - yi;
+        const float iw = in ? 1.0f / fminf(sqrtf(rx * rx + ry * ry), 1.0f) : 0.0f;
+        a.scT = fmaf(iw, tg.z * p.vratio - ci, a.scT);
+        a.ssT = fmaf(iw, tg.w * p.vratio - si, a.ssT);
+        a.cntT += m;
+        a.iwT += iw;
+        a.sxT = fmaf(iw, dx, a.sxT);
+        a.syT = fmaf(iw, dy, a.syT);
+        a.trk = fmaf(m, fmaf(-d, p.inv_dp, 2.0f), a.trk);
+        bits |= (d2 < p.dp2) ? (1u << (k & 31)) : 0u;
+        if ((k & 31) == 31 || k == M - 1) {
+            if (bits) atomicOr(&covw[covbase + (k >> 5)], bits);
+            bits = 0;
+        }
+    }
+#pragma unroll 1
+    for (int j = 0; j < N; ++j) {
+        const bool other = (j != i);
+        const float4 *rs = (j < i) ? rowNew : rowOld;
+        const float4 nw = rowNew[j * 4];
+        const float4 mx = rs[j * 4];
+        const float4 ax = rs[j * 4 + 1];
+        const float am = ax.x;
+        const float dxn = nw.x - xi, dyn = nw.y - yi, dxm = mx.x - xi, dym = mx.y - yi;
+        const v2f sqn = (v2f){dxn, dyn} * (v2f){dxn, dyn}, sqm = (v2f){dxm, dym} * (v2f){dxm, dym};
+        float d2n = sqn.x + sqn.y, d2m = sqm.x + sqm.y;
+        if (Z3) {
+            const float dzn = rowNew[j * 4 + 1].z - zi, dzm = ax.z - zi;
+            d2n = fmaf(dzn, dzn, d2n);
+            d2m = fmaf(dzm, dzm, d2m);
+        }
+        const float ex = fast_exp2(fmaf(fast_sqrt(d2n), -p.exp_k1, p.exp_k0));
+        a.dup += (other && d2n <= p.two_dp2) ? ex : 0.0f;
         const bool inm = other && d2m <= p.dc2;
         const float m = inm ? 1.0f : 0.0f;
-        float iw = m;
-        if (WEIGHTED) {
-            const float rx = dxm * p.inv_dc - xi, ry = dym * p.inv_dc - yi;
-            iw = inm ? 1.0f / fminf(sqrtf(rx * rx + ry * ry), 1.0f) : 0.0f;
-            a.scU = fmaf(iw, mx.z - ci, a.scU);
-            a.ssU = fmaf(iw, mx.w - si, a.ssU);
-            a.saU = fmaf(iw, am - ai, a.saU);
-        } else {
-            a.scU = fmaf(m, mx.z, a.scU);
-            a.ssU = fmaf(m, mx.w, a.ssU);
-            a.saU = fmaf(m, am, a.saU);
-        }
+        const float rx = dxm * p.inv_dc - xi, ry = dym * p.inv_dc - yi;
+        const float iw = inm ? 1.0f / fminf(sqrtf(rx * rx + ry * ry), 1.0f) : 0.0f;
+        a.scU = fmaf(iw, mx.z - ci, a.scU);
+        a.ssU = fmaf(iw, mx.w - si, a.ssU);
+        a.saU = fmaf(iw, am - ai, a.saU);
         a.cntU += m;
         a.iwU += iw;
         a.sxU = fmaf(iw, dxm, a.sxU);
         a.syU = fmaf(iw, dym, a.syU);
-    }
-    if (!WEIGHTED) {
-        // sum_j m (c_j - c_i) = sum_j m c_j - c_i cnt; targets carry the speed ratio
-        a.scT = fmaf(a.scT, p.vratio, -ci * a.cntT);
-        a.ssT = fmaf(a.ssT, p.vratio, -si * a.cntT);
-        a.scU = fmaf(-ci, a.cntU, a.scU);
-        a.ssU = fmaf(-si, a.cntU, a.ssU);
-        a.saU = fmaf(-ai, a.cntU, a.saU);
     }
 }
 
@@ -202,13 +291,15 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     const int nthreads = blockDim.x;
 
     // ---- LDS carve (float4 first: the dynamic base is 16-B aligned)
-    float4 *utab = smem4;                 // [EN][2]  (x, y, cos h, sin h), copy p = post-move of this step
-    float4 *ttab = utab + 2 * EN;         // [EM]     (x, y, cos h, sin h)
+    // UAV table: per (env, uav) two 32-B rows (copy 0 / copy 1, one of them "post-move of this
+    // step"), each (x, y, cos h, sin h | action, 1, z, -).  The env stride carries 32 B of padding so
+    // that rows of different envs read by one lane group start in different banks.
+    const int ustride = N * 4 + 2;        // float4 units per env
+    float4 *utab = smem4;                 // [E][N][2][2]
+    float4 *ttab = utab + E * ustride;    // [EM]     (x, y, cos h, sin h)
     float *fb = reinterpret_cast<float *>(ttab + EM);
-    float *atab = fb;  fb += 2 * EN;      // [EN][2]  action index as float
     float *thd = fb;   fb += EM;          // [EM]     target heading
     float *rawl = fb;  fb += EN;          // [EN]     raw reward (cooperative modes)
-    float *uzt = fb;   if (Z3) fb += 2 * EN;
     float *tzt = fb;   if (Z3) fb += EM;
     unsigned *covw = reinterpret_cast<unsigned *>(fb);   // [2][E * CW]
 
@@ -230,25 +321,27 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     int pn = 0;                                   // which table copy is "post-move" this step
 
     // ---- load state once
+    const StateBlock &S = *p.st;
     if (active) {
-        x = p.ux[g]; y = p.uy[g]; h = p.uh[g]; a_prev = p.ua[g];
-        if (Z3) z = p.uz[g];
-        sincosf(h, &s, &c);
-        count = p.step_count[b];
-        utab[(ebaseU + i) * 2 + 1] = make_float4(x, y, c, s);   // "previous" copy for step 0
-        atab[(ebaseU + i) * 2 + 1] = (float)a_prev;
-        if (Z3) uzt[(ebaseU + i) * 2 + 1] = z;
+        x = S.ux[g]; y = S.uy[g]; h = S.uh[g]; a_prev = S.ua[g];
+        if (Z3) z = S.uz[g];
+        sincos_any(h, &s, &c);
+        count = S.step_count[b];
+        float4 *own = utab + e * ustride + i * 4 + 2;           // "previous" copy for step 0
+        own[0] = make_float4(x, y, c, s);
+        own[1] = make_float4((float)a_prev, 1.0f, z, 0.0f);
     }
     for (int q = tid; q < envs_here * M; q += nthreads) {
         const size_t gt = (size_t)env0 * M + q;
-        const float th = p.th[gt];
+        const float th = S.th[gt];
         float ts, tc;
-        sincosf(th, &ts, &tc);
-        ttab[q] = make_float4(p.tx[gt], p.ty[gt], tc, ts);
+        sincos_any(th, &ts, &tc);
+        ttab[q] = make_float4(S.tx[gt], S.ty[gt], tc, ts);
         thd[q] = th;
-        if (Z3) tzt[q] = p.tz[gt];
+        if (Z3) tzt[q] = S.tz[gt];
     }
-    for (int q = tid; q < 2 * E * CW; q += nthreads) covw[q] = 0;
+    if (active && i == 0)
+        for (int w = 0; w < CW; ++w) covw[e * CW + w] = covw[E * CW + e * CW + w] = 0;
     int act = 0;
     if (active) act = p.actions[g];
     __syncthreads();
@@ -272,7 +365,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                 turned = true;
             }
             if (turned) {   // rare: recompute so that T fused steps == T single steps bit for bit
-                sincosf(th, &tg.w, &tg.z);
+                sincos_any(th, &tg.w, &tg.z);
                 thd[q] = th;
             }
             ttab[q] = tg;
@@ -281,26 +374,28 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         // ---- P1b: own kinematics (uav.py:83-99); position uses the OLD heading
         int a_now = 0;
         float ai = 0;
+        float xo = x, yo = y, zo = z, co = c, so = s, ao = (float)a_prev;   // pre-move pose: the j == i self term
         if (active) {
             a_now = min(max(act, 0), p.na_total - 1);
             int a_turn = a_now, a_climb = 0;
             if (Z3) { a_climb = a_now / p.na; a_turn = a_now - a_climb * p.na; }
             float step_xy = p.dtv_u;
             if (Z3) {
-                step_xy = p.dtv_u * p.climb_c[a_climb];
-                z = fmaf(p.dtv_u, p.climb_s[a_climb], z);
+                step_xy = p.dtv_u * S.climb_c[a_climb];
+                z = fmaf(p.dtv_u, S.climb_s[a_climb], z);
             }
             x = fmaf(step_xy, c, x);
             y = fmaf(step_xy, s, y);
             h = wrap_heading(fmaf((float)(2 * a_turn + 1 - p.na), p.turn_unit, h));
-            sincosf(h, &s, &c);
+            sincos_wrapped(h, &s, &c);
             ai = (float)a_now;
-            utab[(ebaseU + i) * 2 + pn] = make_float4(x, y, c, s);
-            atab[(ebaseU + i) * 2 + pn] = ai;
-            if (Z3) uzt[(ebaseU + i) * 2 + pn] = z;
+            float4 *own = utab + e * ustride + i * 4 + pn * 2;
+            own[0] = make_float4(x, y, c, s);
+            own[1] = make_float4(ai, 1.0f, z, 0.0f);
             if (t + 1 < p.T) act = p.actions[tg_off + BN];   // prefetch next step's action
         }
-        for (int q = tid; q < E * CW; q += nthreads) covw[cbuf + q] = 0;
+        if (active && i == 0)
+            for (int w = 0; w < CW; ++w) covw[cbuf + e * CW + w] = 0;
         __syncthreads();
 
         // ---- P2: pair sweeps
@@ -309,12 +404,14 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             Acc acc;
             // weight of uav.py:165 can be < 1 only near the origin; wave-uniform branch
             const bool near0 = fabsf(x) < 2.5f && fabsf(y) < 2.5f;
+            const float4 *rowNew = utab + e * ustride + pn * 2;
+            const float4 *rowOld = utab + e * ustride + (pn ^ 1) * 2;
             if (__builtin_expect(__any(near0), 0))
-                sweep<N_, M_, Z3, true>(p, N, M, ebaseU, ebaseT, i, pn, utab, atab, uzt, ttab, tzt, covw,
-                                        cbuf + e * CW, x, y, z, c, s, ai, acc);
+                sweep_weighted<N_, M_, Z3>(p, N, M, ebaseT, i, rowNew, rowOld, ttab, tzt, covw,
+                                           cbuf + e * CW, x, y, z, c, s, ai, acc);
             else
-                sweep<N_, M_, Z3, false>(p, N, M, ebaseU, ebaseT, i, pn, utab, atab, uzt, ttab, tzt, covw,
-                                         cbuf + e * CW, x, y, z, c, s, ai, acc);
+                sweep_fast<N_, M_, Z3>(p, N, M, ebaseT, i, rowNew, rowOld, ttab, tzt, covw,
+                                       cbuf + e * CW, x, y, z, c, s, ai, xo, yo, zo, co, so, ao, acc);
 
             // ---- P3: local state (uav.py:156-190)
             if (acc.cntU > 0.0f) {
@@ -358,12 +455,14 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             if (MODE == UAVTRACK_REWARD_MEAN) {
                 if (p.coop != 0.0f) {   // uav.py:293-310
                     float sum = 0, cnt = 0;
+                    const float4 *rowNew = utab + e * ustride + pn * 2;
 #pragma unroll UAVTRACK_UNROLL_U
                     for (int j = 0; j < (N_ > 0 ? N_ : N); ++j) {
-                        const float4 nw = utab[(ebaseU + j) * 2 + pn];
-                        const float dx = nw.x - x, dy = nw.y - y;
-                        float d2 = dx * dx + dy * dy;
-                        if (Z3) { const float dz = uzt[(ebaseU + j) * 2 + pn] - z; d2 += dz * dz; }
+                        const float4 nw = rowNew[j * 4];
+                        const v2f dd = (v2f){nw.x, nw.y} - (v2f){x, y};
+                        const v2f sq = dd * dd;                  // same products as the sweeps
+                        float d2 = sq.x + sq.y;
+                        if (Z3) { const float dz = rowNew[j * 4 + 1].z - z; d2 = fmaf(dz, dz, d2); }
                         const bool nb = (j != i) && d2 <= p.dp2;
                         sum += nb ? rawl[ebaseU + j] : 0.0f;
                         cnt += nb ? 1.0f : 0.0f;
@@ -405,14 +504,14 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
 
     // ---- store state once
     if (active) {
-        p.ux[g] = x; p.uy[g] = y; p.uh[g] = h; p.ua[g] = a_prev;
-        if (Z3) p.uz[g] = z;
-        if (i == 0) p.step_count[b] = count;
+        S.ux[g] = x; S.uy[g] = y; S.uh[g] = h; S.ua[g] = a_prev;
+        if (Z3) S.uz[g] = z;
+        if (i == 0) S.step_count[b] = count;
     }
     for (int q = tid; q < envs_here * M; q += nthreads) {
         const size_t gt = (size_t)env0 * M + q;
         const float4 tg = ttab[q];
-        p.tx[gt] = tg.x; p.ty[gt] = tg.y; p.th[gt] = thd[q];
+        S.tx[gt] = tg.x; S.ty[gt] = tg.y; S.th[gt] = thd[q];
     }
     if (p.ep_sums) {
         __syncthreads();                       // everyone is done with utab
@@ -436,8 +535,8 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
 size_t lds_bytes_for(int E, int N, int M, bool z3)
 {
     const size_t EN = (size_t)E * N, EM = (size_t)E * M, CW = (M + 31) / 32;
-    size_t f4 = 2 * EN + EM;
-    size_t f = 2 * EN + EM + EN + (z3 ? 2 * EN + EM : 0) + 2 * E * CW;
+    size_t f4 = (size_t)E * (N * 4 + 2) + EM;
+    size_t f = EM + EN + (z3 ? EM : 0) + 2 * E * CW;
     return f4 * 16 + f * 4;
 }
 
@@ -490,9 +589,10 @@ Geometry plan_geometry(const uavtrack_config &cfg)
         if (forced && wgs != forced) continue;
         const int E = wgs / N;
         if (E < 1) continue;
+        if (lds_bytes_for(E, N, cfg.m_targets, cfg.dim == 3) > 64 * 1024) continue;   // e.g. N = 1 with many targets
         const int Euse = E < cfg.n_envs ? E : cfg.n_envs;
         const double util = (double)Euse * N / wgs;
-        if (util > best_util + 0.02) { best_util = util; best = wgs; }
+        if (util > best_util + 0.05) { best_util = util; best = wgs; }
     }
     if (!best && forced >= 64 && forced <= kMaxWorkgroup && forced % 64 == 0 && forced / N >= 1) best = forced;
     if (!best) return g;

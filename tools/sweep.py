@@ -8,7 +8,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--lib"); ap.add_argument("--envs", type=int, default=4096); ap.add_argument("--T", type=int, default=200)
 ap.add_argument("--n", type=int, default=20); ap.add_argument("--m", type=int, default=10)
 ap.add_argument("--coop", type=float, default=0.0); ap.add_argument("--wgs", default="0")
-ap.add_argument("--reps", type=int, default=5); ap.add_argument("--dim", type=int, default=2)
+ap.add_argument("--reps", type=int, default=5); ap.add_argument("--no-obs", action="store_true"); ap.add_argument("--no-terms", action="store_true"); ap.add_argument("--dim", type=int, default=2)
 a = ap.parse_args()
 import torch
 import uavtrack
@@ -22,12 +22,12 @@ for wgs in [int(w) for w in a.wgs.split(",")]:
     env = uavtrack.BatchedUavEnv(cfg)
     env.reset(seed=1)
     act = torch.randint(0, cfg.na_total, (a.T, a.envs, a.n), dtype=torch.int32, device="cuda")
-    out = env.step_many(act)
+    out = env.step_many(act, want_obs=not a.no_obs, want_terms=not a.no_terms)
     torch.cuda.synchronize()
     best = []
     for r in range(a.reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); out = env.step_many(act, out=out); e1.record(); torch.cuda.synchronize()
+        e0.record(); out = env.step_many(act, out=out, want_obs=not a.no_obs, want_terms=not a.no_terms); e1.record(); torch.cuda.synchronize()
         best.append(e0.elapsed_time(e1))
     ms = sorted(best)[len(best) // 2]
     rate = a.envs * a.n * a.T / (ms * 1e-3)
