@@ -44,7 +44,8 @@ void free_state(uavtrack_env *env)
 {
     StateBlock &s = env->state;
     void *ptrs[] = {s.ux, s.uy, s.uz, s.uh, s.ua, s.tx, s.ty, s.tz, s.th, s.step_count,
-                    env->d_state, env->pmi.blob, env->pmi_scratch};
+                    env->d_state, env->pmi.blob, env->pairs, env->pair_count, env->scores, env->raw,
+                    env->obs_tmp, env->terms_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -266,7 +267,9 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
         env->pmi = PmiWeights();
         return 0;
     }
-    if (hidden < 1 || hidden > 1024) return fail("uavtrack_set_pmi_weights: hidden must be in [1, 1024]");
+    if (!pmi_hidden_supported(hidden))
+        return fail("uavtrack_set_pmi_weights: hidden %d not built; this build has the MFMA scorer for 64 and 128 "
+                    "(configs/MAAC-R.yaml uses 128, PMINetwork's default is 64)", hidden);
     const size_t H = (size_t)hidden;
     const size_t want = 12 * H + 3 * H + 3 * H * H + H + H + 1;
     if (n_floats != want)
@@ -282,6 +285,18 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
     HIP_TRY(hipStreamSynchronize(st));
     env->pmi.hidden = hidden;
     env->pmi.n_floats = n_floats;
+    if (!env->pairs) {   // MAAC-R scratch, sized for the worst case (every pair within dp)
+        const uavtrack_config &c = env->cfg;
+        const size_t BN = (size_t)c.n_envs * c.n_uav;
+        const size_t max_pairs = (size_t)c.n_envs * c.n_uav * (c.n_uav - 1) / 2;
+        HIP_TRY(dmalloc(&env->pairs, max_pairs));
+        HIP_TRY(dmalloc(&env->pair_count, 1));
+        HIP_TRY(dmalloc(&env->scores, BN * c.n_uav));
+        HIP_TRY(dmalloc(&env->raw, BN));
+        HIP_TRY(dmalloc(&env->obs_tmp, BN * UAVTRACK_OBS_DIM));
+        HIP_TRY(dmalloc(&env->terms_tmp, 3 * BN));
+        HIP_TRY(hipMemsetAsync(env->scores, 0, BN * c.n_uav * sizeof(float), st));
+    }
     return 0;
 }
 
@@ -292,15 +307,43 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
     if (T < 1) return fail("%s: T must be >= 1 (got %d)", who, T);
     if (!actions) return fail("%s: actions is null", who);
     if (!reward) return fail("%s: reward is null", who);
-    if (env->cfg.reward_mode == UAVTRACK_REWARD_PMI)
-        return fail("%s: reward_mode PMI is not implemented in this build", who);
     HIP_TRY(hipSetDevice(env->cfg.device_id));
+    hipStream_t st = static_cast<hipStream_t>(stream);
     StepParams p = env->base;
-    p.T = T;
     p.actions = actions;
     p.obs = obs; p.reward = reward; p.terms = terms; p.raw_out = nullptr;
     p.covered = covered; p.done = done; p.ep_sums = ep_sums;
-    HIP_TRY(launch_rollout(env, p, static_cast<hipStream_t>(stream)));
+    p.pairs = nullptr; p.pair_count = nullptr;
+    if (env->cfg.reward_mode != UAVTRACK_REWARD_PMI) {
+        p.T = T;
+        HIP_TRY(launch_rollout(env, p, st));
+        return 0;
+    }
+    // MAAC-R: per step, the fused kernel (observations, raw rewards, neighbour pair list), the
+    // MFMA pair scorer, and the softmax mix; everything stream-ordered, nothing on the host.
+    if (!env->pmi.blob) return fail("%s: reward_mode PMI needs uavtrack_set_pmi_weights first", who);
+    const uavtrack_config &c = env->cfg;
+    const size_t BN = (size_t)c.n_envs * c.n_uav;
+    if (ep_sums) HIP_TRY(hipMemsetAsync(ep_sums, 0, (size_t)c.n_envs * 5 * sizeof(float), st));
+    p.T = 1;
+    p.ep_sums = nullptr;
+    p.raw_out = env->raw;
+    p.pairs = env->pairs;
+    p.pair_count = env->pair_count;
+    for (int32_t t = 0; t < T; ++t) {
+        float *obs_t = obs ? obs + (size_t)t * BN * UAVTRACK_OBS_DIM : env->obs_tmp;
+        float *terms_t = terms ? terms + (size_t)t * 3 * BN : (ep_sums ? env->terms_tmp : nullptr);
+        float *reward_t = reward + (size_t)t * BN;
+        int32_t *covered_t = covered ? covered + (size_t)t * c.n_envs : nullptr;
+        p.actions = actions + (size_t)t * BN;
+        p.obs = obs_t; p.reward = reward_t; p.terms = terms_t;
+        p.covered = covered_t;
+        p.done = done ? done + (size_t)t * c.n_envs : nullptr;
+        HIP_TRY(hipMemsetAsync(env->pair_count, 0, sizeof(unsigned), st));
+        HIP_TRY(launch_rollout(env, p, st));
+        HIP_TRY(launch_pmi_score(env, obs_t, st));
+        HIP_TRY(launch_pmi_finalize(env, reward_t, terms_t, covered_t, ep_sums, st));
+    }
     return 0;
 }
 

@@ -34,6 +34,8 @@ struct StepParams {
     int32_t *covered;
     uint8_t *done;
     float *ep_sums;
+    uint2 *pairs;            // MAAC-R: neighbour pair list {flat agent index of i, j}, i < j
+    unsigned *pair_count;
     // geometry
     int32_t B, N, M, E, T, na, na_total, horizon;
     // constants
@@ -72,9 +74,13 @@ struct uavtrack_env {
     uavtrack::StateBlock *d_state = nullptr;
     uavtrack::Geometry geo;
     uavtrack::PmiWeights pmi;
-    // PMI scratch (allocated on first use)
+    // MAAC-R scratch, allocated with the weights: pair list + counter, dense score matrix
+    // [B][N][N], raw reward [B][N], and an observation buffer for callers that pass obs = NULL
     void *pmi_scratch = nullptr;
     size_t pmi_scratch_bytes = 0;
+    uint2 *pairs = nullptr;
+    unsigned *pair_count = nullptr;
+    float *scores = nullptr, *raw = nullptr, *obs_tmp = nullptr, *terms_tmp = nullptr;
 };
 
 namespace uavtrack {
@@ -82,6 +88,12 @@ namespace uavtrack {
 // step_kernel.hip
 Geometry plan_geometry(const uavtrack_config &cfg);
 hipError_t launch_rollout(const uavtrack_env *env, const StepParams &p, hipStream_t stream);
+
+// pmi_kernel.hip
+bool pmi_hidden_supported(int hidden);
+hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream_t stream);
+hipError_t launch_pmi_finalize(const uavtrack_env *env, float *reward, const float *terms, const int32_t *covered,
+                               float *ep_sums, hipStream_t stream);
 
 // reset_kernel.hip
 hipError_t launch_reset(const uavtrack_env *env, uint64_t seed, uint32_t episode, float *obs,

@@ -1,0 +1,273 @@
+// pmi_kernel.hip -- the MAAC-R cooperative reward (reference src/agent/uav.py:262-291),
+// i.e. PMINetwork.inference (src/models/PMINet.py:41-72, eval mode) on every neighbour
+// pair, then the per-UAV softmax mix.
+//
+// This is the one dense contraction on the path: per pair a 12 -> 3H -> H -> 1 MLP whose
+// 3H x H layer is 98 % of the work (2*3H*H = 98 304 FLOP at H = 128).  The reference runs it
+// in fp32 torch, so it is kept in exact fp32 on the matrix cores:
+// v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fmaf chain.
+//
+// pmi_score_kernel<H>: weight-stationary.  A workgroup has H/32 wavefronts; wavefront w owns
+// the 32 output columns [32w, 32w+32) of the folded fc1 matrix and keeps its whole
+// 3H x 32 slice in registers (3H/2 VGPRs per lane -- 192 at H = 128) for the lifetime of the
+// (persistent, grid-striding) workgroup, so in steady state no weight byte moves.  Per tile
+// of 32 pairs: all threads gather the two 12-float observations of their pair from HBM/L2,
+// form x = la_i * la_j, run the three small branch layers (5/4/3 -> H, BatchNorm folded,
+// ReLU) on the VALU from LDS-resident weights and write the 32 x 3H activation tile to LDS
+// in MFMA A-operand order; then each wavefront runs 3H/2 back-to-back MFMAs reading one
+// ds_read_b128 per four of them.  Epilogue: ReLU, times fc2, fixed-order lane reduction,
+// fixed-order sum over the H/32 column blocks -> s_ij, stored at [b][i][j] and [b][j][i].
+//
+// pmi_finalize_kernel: one thread per UAV: neighbours in index order, max-shifted softmax of
+// their scores (scipy.special.softmax, uav.py:287), reward = (1-a) raw_i + a sum_j w_j raw_j,
+// (1-a) raw_i without neighbours (uav.py:290), final clip (environment.py:225).
+
+#include "internal.h"
+
+namespace uavtrack {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct PmiParams {
+    const float *blob;       // folded weights, layout of uavtrack_set_pmi_weights
+    const float *obs;        // [B][N][12] local states of this step
+    const uint2 *pairs;      // {flat agent index of i, j}
+    const unsigned *pair_count;
+    float *scores;           // [B][N][N]
+    int32_t N;
+};
+
+template <int H>
+__global__ void __launch_bounds__(H * 2) pmi_score_kernel(const PmiParams q)
+{
+    constexpr int K = 3 * H;             // fc1 input width
+    constexpr int KH = K / 2;            // MFMA k-steps (32x32x2)
+    constexpr int ROW = KH + 4;          // padded LDS row: 32 rows of one k-parity never share a bank slot
+    constexpr int NW = H / 32;           // wavefronts = column blocks
+    constexpr int NT = NW * 64;          // threads
+    constexpr int GROUPS = NT / 32;      // threads per pair in the branch layers
+    constexpr int PER = H / GROUPS;      // outputs per thread per branch
+
+    __shared__ float4 lds4[(2 * 32 * ROW + 12 * H + 3 * H + NW * 32) / 4 + 2];
+    float *h0s = reinterpret_cast<float *>(lds4);          // [2][32][ROW]  (k parity, pair, k/2)
+    float *wa = h0s + 2 * 32 * ROW;                        // Wc[5][H] bc[H] Wo[4][H] bo[H] Wb[3][H] bb[H]
+    float *part = wa + 15 * H;                             // [NW][32] per-column-block partial scores
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int col = w * 32 + (lane & 31);
+    const int kh = lane >> 5;
+
+    // ---- stationary operands
+    const float *W1 = q.blob + 15 * H;                     // [3H][H], input-major
+    const float *b1 = W1 + (size_t)K * H;
+    const float *w2 = b1 + H;
+    const float b2 = w2[H];
+    float breg[KH];
+#pragma unroll
+    for (int t = 0; t < KH; ++t) breg[t] = W1[(size_t)(2 * t + kh) * H + col];   // B[k = 2t + kh][col]
+    const float bias1 = b1[col], wout = w2[col];
+    for (int k = tid; k < 15 * H; k += NT) wa[k] = q.blob[k];
+    __syncthreads();
+
+    const unsigned npairs = *q.pair_count;
+    const unsigned ntiles = (npairs + 31) >> 5;
+    const int p = tid & 31;              // pair of this thread in the branch layers
+    const int grp = tid >> 5;            // which slice of the H outputs of each branch
+
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // ---- gather + branch layers (PMINet.py:50-55), x = la_i * la_j (uav.py:281)
+        const unsigned pi = tile * 32 + p;
+        float x[12];
+        uint2 pr = make_uint2(0, 0);
+        if (pi < npairs) {
+            pr = q.pairs[pi];
+            const unsigned gi = pr.x, gj = (pr.x / q.N) * q.N + pr.y;
+            const float4 *oi = reinterpret_cast<const float4 *>(q.obs + (size_t)gi * 12);
+            const float4 *oj = reinterpret_cast<const float4 *>(q.obs + (size_t)gj * 12);
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const float4 a = oi[v], b = oj[v];
+                x[4 * v + 0] = a.x * b.x; x[4 * v + 1] = a.y * b.y;
+                x[4 * v + 2] = a.z * b.z; x[4 * v + 3] = a.w * b.w;
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < 12; ++v) x[v] = 0.0f;
+        }
+#pragma unroll
+        for (int m = 0; m < PER; ++m) {
+            const int o = grp + GROUPS * m;                 // output index within a branch, 0..H-1
+            float c = wa[5 * H + o];
+#pragma unroll
+            for (int v = 0; v < 5; ++v) c = fmaf(wa[v * H + o], x[v], c);
+            float ob = wa[6 * H + 4 * H + o];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) ob = fmaf(wa[6 * H + v * H + o], x[5 + v], ob);
+            float bs = wa[11 * H + 3 * H + o];
+#pragma unroll
+            for (int v = 0; v < 3; ++v) bs = fmaf(wa[11 * H + v * H + o], x[9 + v], bs);
+            // concat order (PMINet.py:58): comm | obs | boundary_state ; k -> (parity k&1, step k>>1)
+            const int k0 = o, k1 = H + o, k2 = 2 * H + o;
+            h0s[((k0 & 1) * 32 + p) * ROW + (k0 >> 1)] = fmaxf(c, 0.0f);
+            h0s[((k1 & 1) * 32 + p) * ROW + (k1 >> 1)] = fmaxf(ob, 0.0f);
+            h0s[((k2 & 1) * 32 + p) * ROW + (k2 >> 1)] = fmaxf(bs, 0.0f);
+        }
+        __syncthreads();
+
+        // ---- fc1 (+ folded bn1) on the matrix cores: [32 pairs x 3H] x [3H x 32 cols]
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bias1;
+        const float4 *arow = reinterpret_cast<const float4 *>(h0s + (kh * 32 + (lane & 31)) * ROW);
+#pragma unroll
+        for (int t4 = 0; t4 < KH / 4; ++t4) {
+            const float4 a4 = arow[t4];                     // A[pair][k = 2t + kh], t = 4 t4 .. 4 t4 + 3
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, breg[4 * t4 + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, breg[4 * t4 + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, breg[4 * t4 + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, breg[4 * t4 + 3], acc, 0, 0, 0);
+        }
+
+        // ---- ReLU, fc2 (PMINet.py:60-61): per row, sum over this block's 32 columns in a fixed
+        //      butterfly order (bitwise reproducible), then over the column blocks in order
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = fmaxf(acc[r], 0.0f) * wout;
+#pragma unroll
+            for (int msk = 1; msk < 32; msk <<= 1) v += __shfl_xor(v, msk, 64);
+            // C/D layout of 32x32 MFMA: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+            if ((lane & 31) == 0) part[w * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh] = v;
+        }
+        __syncthreads();
+        if (tid < 32 && tile * 32 + tid < npairs) {
+            float sc = b2;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) sc += part[ww * 32 + tid];
+            const unsigned gi = pr.x, bidx = pr.x / q.N, ii = pr.x - bidx * q.N, jj = pr.y;
+            q.scores[(size_t)gi * q.N + jj] = sc;
+            q.scores[((size_t)bidx * q.N + jj) * q.N + ii] = sc;
+        }
+        __syncthreads();   // h0s / part are rewritten by the next tile
+    }
+}
+
+struct FinalizeParams {
+    const float *ux, *uy, *uz;
+    const float *raw, *scores;
+    float *reward;
+    int32_t B, N, three_d;
+    float dp2, coop;
+};
+
+__global__ void __launch_bounds__(256) pmi_finalize_kernel(const FinalizeParams f)
+{
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)f.B * f.N) return;
+    const int b = (int)(gid / f.N), i = (int)(gid - (long long)b * f.N);
+    const size_t e0 = (size_t)b * f.N;
+    const float x = f.ux[gid], y = f.uy[gid], z = f.three_d ? f.uz[gid] : 0.0f;
+    const float raw_i = f.raw[gid];
+    const float *srow = f.scores + (size_t)gid * f.N;
+    // pass 1: max score over neighbours (same d2 expression as the pair emission in the step kernel)
+    float mx = -INFINITY;
+    int cnt = 0;
+    for (int j = 0; j < f.N; ++j) {
+        const v2f dd = (v2f){f.ux[e0 + j], f.uy[e0 + j]} - (v2f){x, y};
+        const v2f sq = dd * dd;
+        float d2 = sq.x + sq.y;
+        if (f.three_d) { const float dz = f.uz[e0 + j] - z; d2 = fmaf(dz, dz, d2); }
+        if (j != i && d2 <= f.dp2) { mx = fmaxf(mx, srow[j]); ++cnt; }
+    }
+    float r = (1.0f - f.coop) * raw_i;                               // uav.py:290
+    if (cnt) {
+        float den = 0.0f, num = 0.0f;
+        for (int j = 0; j < f.N; ++j) {
+            const v2f dd = (v2f){f.ux[e0 + j], f.uy[e0 + j]} - (v2f){x, y};
+            const v2f sq = dd * dd;
+            float d2 = sq.x + sq.y;
+            if (f.three_d) { const float dz = f.uz[e0 + j] - z; d2 = fmaf(dz, dz, d2); }
+            if (j != i && d2 <= f.dp2) {
+                const float ew = expf(srow[j] - mx);
+                den += ew;
+                num = fmaf(ew, f.raw[e0 + j], num);
+            }
+        }
+        r = fmaf(f.coop, num / den, r);                              // uav.py:288
+    }
+    f.reward[gid] = fminf(fmaxf(r, -1.0f), 1.0f);                    // environment.py:225
+}
+
+// train.py:181-192 accumulators for the MAAC-R path (the fused kernel does this in-register)
+struct EpParams {
+    const float *reward, *terms;
+    const int32_t *covered;
+    float *ep_sums;
+    int32_t B, N;
+};
+
+__global__ void __launch_bounds__(256) ep_accumulate_kernel(const EpParams q)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= q.B) return;
+    const size_t BN = (size_t)q.B * q.N;
+    float s[4] = {0, 0, 0, 0};
+    for (int i = 0; i < q.N; ++i) {
+        const size_t g = (size_t)b * q.N + i;
+        s[0] += q.reward[g];
+        if (q.terms) { s[1] += q.terms[g]; s[2] += q.terms[BN + g]; s[3] += q.terms[2 * BN + g]; }
+    }
+    const float inv = 1.0f / (float)q.N;
+    float *ep = q.ep_sums + (size_t)b * 5;
+    ep[0] += s[0] * inv; ep[1] += s[1] * inv; ep[2] += s[2] * inv; ep[3] += s[3] * inv;
+    if (q.covered) ep[4] += (float)q.covered[b];
+}
+
+}  // namespace
+
+bool pmi_hidden_supported(int hidden) { return hidden == 64 || hidden == 128; }
+
+hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream_t stream)
+{
+    PmiParams q;
+    q.blob = env->pmi.blob;
+    q.obs = obs;
+    q.pairs = env->pairs;
+    q.pair_count = env->pair_count;
+    q.scores = env->scores;
+    q.N = env->cfg.n_uav;
+    // persistent workgroups grid-striding over 32-pair tiles: one per CU at H = 128 (288 registers per
+    // lane leave room for one wavefront per SIMD), two at H = 64
+    const int grid = env->pmi.hidden == 128 ? 256 : 512;
+    if (env->pmi.hidden == 128)
+        hipLaunchKernelGGL(pmi_score_kernel<128>, dim3(grid), dim3(256), 0, stream, q);
+    else if (env->pmi.hidden == 64)
+        hipLaunchKernelGGL(pmi_score_kernel<64>, dim3(grid), dim3(128), 0, stream, q);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_pmi_finalize(const uavtrack_env *env, float *reward, const float *terms, const int32_t *covered,
+                               float *ep_sums, hipStream_t stream)
+{
+    const uavtrack_config &c = env->cfg;
+    FinalizeParams f;
+    f.ux = env->state.ux; f.uy = env->state.uy; f.uz = env->state.uz;
+    f.raw = env->raw; f.scores = env->scores; f.reward = reward;
+    f.B = c.n_envs; f.N = c.n_uav; f.three_d = c.dim == 3;
+    f.dp2 = env->base.dp2; f.coop = env->base.coop;
+    const long long total = (long long)c.n_envs * c.n_uav;
+    hipLaunchKernelGGL(pmi_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, f);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !ep_sums) return e;
+    EpParams q{reward, terms, covered, ep_sums, c.n_envs, c.n_uav};
+    hipLaunchKernelGGL(ep_accumulate_kernel, dim3((unsigned)((c.n_envs + 255) / 256)), dim3(256), 0, stream, q);
+    return hipGetLastError();
+}
+
+}  // namespace uavtrack

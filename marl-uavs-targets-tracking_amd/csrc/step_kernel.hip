@@ -499,6 +499,42 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             }
             a_prev = a_now;
         }
+
+        // ---- MAAC-R only: emit the neighbour pairs (i < j, d <= dp on post-move poses, uav.py:278) this
+        //      workgroup owns into the global pair list the PMI scoring kernel consumes.  s_ij = s_ji
+        //      (the input is la_i * la_j), so unordered pairs halve the work.
+        if (MODE == UAVTRACK_REWARD_PMI) {
+            unsigned *wg_cnt = covw + 2 * E * CW;          // two extra words behind the coverage masks
+            if (tid == 0) wg_cnt[0] = 0;
+            __syncthreads();
+            int mine = 0, slot = 0;
+            const float4 *rowNew = utab + e * ustride + pn * 2;
+            if (active) {
+                for (int j = i + 1; j < N; ++j) {
+                    const float4 nw = rowNew[j * 4];
+                    const v2f dd = (v2f){nw.x, nw.y} - (v2f){x, y};
+                    const v2f sq = dd * dd;
+                    float d2 = sq.x + sq.y;
+                    if (Z3) { const float dz = rowNew[j * 4 + 1].z - z; d2 = fmaf(dz, dz, d2); }
+                    mine += (d2 <= p.dp2) ? 1 : 0;
+                }
+                if (mine) slot = (int)atomicAdd(&wg_cnt[0], (unsigned)mine);
+            }
+            __syncthreads();
+            if (tid == 0) wg_cnt[1] = wg_cnt[0] ? atomicAdd(p.pair_count, wg_cnt[0]) : 0u;
+            __syncthreads();
+            if (active && mine) {
+                uint2 *dst = p.pairs + wg_cnt[1] + slot;
+                for (int j = i + 1; j < N; ++j) {
+                    const float4 nw = rowNew[j * 4];
+                    const v2f dd = (v2f){nw.x, nw.y} - (v2f){x, y};
+                    const v2f sq = dd * dd;
+                    float d2 = sq.x + sq.y;
+                    if (Z3) { const float dz = rowNew[j * 4 + 1].z - z; d2 = fmaf(dz, dz, d2); }
+                    if (d2 <= p.dp2) *dst++ = make_uint2((unsigned)g, (unsigned)j);
+                }
+            }
+        }
         pn ^= 1;
     }
 
@@ -536,7 +572,7 @@ size_t lds_bytes_for(int E, int N, int M, bool z3)
 {
     const size_t EN = (size_t)E * N, EM = (size_t)E * M, CW = (M + 31) / 32;
     size_t f4 = (size_t)E * (N * 4 + 2) + EM;
-    size_t f = EM + EN + (z3 ? EM : 0) + 2 * E * CW;
+    size_t f = EM + EN + (z3 ? EM : 0) + 2 * E * CW + 2;
     return f4 * 16 + f * 4;
 }
 

@@ -123,6 +123,104 @@ def test_3d_restricted_to_plane_equals_2d_bitwise(uavtrack):
         assert torch.equal(o2[k], o3[k]), k
 
 
+def random_pmi_state_dict(hidden, seed):
+    """A PMINetwork-shaped state_dict (PMINet.py:29-38) with non-trivial BatchNorm statistics."""
+    r = np.random.RandomState(seed)
+    sd = {}
+    for lin, bn, fan_in in (("fc_comm", "bn_comm", 5), ("fc_obs", "bn_obs", 4),
+                            ("fc_boundary_state", "bn_boundary_state", 3), ("fc1", "bn1", 3 * hidden)):
+        k = 1.0 / np.sqrt(fan_in)
+        sd[lin + ".weight"] = r.uniform(-k, k, (hidden, fan_in)).astype(np.float32)
+        sd[lin + ".bias"] = r.uniform(-k, k, hidden).astype(np.float32)
+        sd[bn + ".weight"] = r.uniform(0.5, 1.5, hidden).astype(np.float32)
+        sd[bn + ".bias"] = (r.randn(hidden) * 0.2).astype(np.float32)
+        sd[bn + ".running_mean"] = (r.randn(hidden) * 0.3).astype(np.float32)
+        sd[bn + ".running_var"] = r.uniform(0.5, 2.0, hidden).astype(np.float32)
+    k = 1.0 / np.sqrt(hidden)
+    sd["fc2.weight"] = r.uniform(-k, k, (1, hidden)).astype(np.float32)
+    sd["fc2.bias"] = r.uniform(-k, k, 1).astype(np.float32)
+    return sd
+
+
+@pytest.mark.parametrize("N,M,B,hidden,box", [(20, 10, 128, 128, 2000.0), (20, 10, 96, 128, 500.0), (50, 25, 24, 128, 2000.0),
+                                              (20, 10, 64, 64, 700.0), (7, 4, 50, 128, 600.0), (5, 3, 40, 64, 2000.0)])
+def test_pmi_reward_teacher_forced_vs_oracle(uavtrack, pmi_state_dict, N, M, B, hidden, box):
+    """MAAC-R (BASELINE configs[2]): PMI-softmax weighted neighbour rewards (uav.py:262-291) with the
+    BatchNorm-folded PMINetwork on the matrix cores, against the unfolded fp64 oracle."""
+    from oracle import OraclePmi
+    sd = pmi_state_dict if hidden == 128 else random_pmi_state_dict(hidden, 3)
+    kw = dict(n_envs=B, n_uav=N, m_targets=M, cooperative=0.3, x_max=box, y_max=box)
+    env = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(reward_mode=uavtrack.RewardMode.PMI, **kw))
+    env.set_pmi(sd)
+    env.reset(seed=21)
+    orc = OracleEnv(OracleConfig(**kw), n_threads=8)
+    orc.pmi = OraclePmi.from_state_dict(sd)
+    rng = np.random.RandomState(8)
+    saw_pairs = 0
+    for t in range(5):
+        act = rng.randint(0, 12, size=(B, N)).astype(np.int32)
+        compare_step(env, orc, act, f"PMI N{N} H{hidden} t{t}", min_ok_frac=0.5)
+        saw_pairs += int((np.abs(env.info["terms"].cpu().numpy()[2]) > 0.04).sum())
+    assert saw_pairs > 0       # neighbours existed, so the network really ran
+
+
+def test_pmi_against_reference_goldens(uavtrack, pmi_state_dict):
+    """HIP MAAC-R reward vs the REAL reference's recorded rewards (g4: N20 M10, g5b: N50 M25)."""
+    for name in ("g4_n20m10_pmi", "g5b_n50m25_pmi"):
+        z, meta = load_golden(name)
+        N, M = meta["n_uav"], meta["m_targets"]
+        E, T = len(meta["seeds"]), meta["steps"]
+        B = E * T
+        pick = lambda k: z[k][:, :T].reshape(B, -1)
+        kw = dict(n_envs=B, n_uav=N, m_targets=M, cooperative=0.3)
+        env = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(reward_mode=uavtrack.RewardMode.PMI, **kw))
+        env.set_pmi(pmi_state_dict)
+        env.set_state(**{k: pick(k) for k in ("ux", "uy", "uh", "ua", "tx", "ty", "th")})
+        act = z["actions"].reshape(B, N).astype(np.int32)
+        orc = OracleEnv(OracleConfig(**kw), n_threads=8)
+        inject(orc, host(env.get_state()))
+        ok = orc.step(act)["margin"] > 5e-3
+        obs, rew, _ = env.step(torch.from_numpy(act))
+        np.testing.assert_allclose(rew.cpu().numpy()[ok], z["reward"].reshape(B, N)[ok], rtol=0, atol=2e-5, err_msg=name)
+        np.testing.assert_allclose(obs.cpu().numpy()[ok], z["obs"].reshape(B, N, 12)[ok], rtol=0, atol=2e-5, err_msg=name)
+        # the cooperative term really moved the reward away from the raw one somewhere
+        assert np.abs(z["reward"] - z["raw"]).max() > 1e-3
+
+
+def test_pmi_edge_cases_and_step_many(uavtrack, pmi_state_dict):
+    z, meta = load_golden("g7_edges")
+    for case in meta["cases"]:
+        if not case["pmi"]:
+            continue
+        name, N, M = case["name"], case["n_uav"], case["m_targets"]
+        cfg = uavtrack.EnvConfig(n_envs=1, n_uav=N, m_targets=M, cooperative=0.3, reward_mode=uavtrack.RewardMode.PMI)
+        env = uavtrack.BatchedUavEnv(cfg)
+        env.set_pmi(pmi_state_dict)
+        g = lambda k: z[f"{name}__{k}"]
+        for t in range(case["steps"]):
+            env.set_state(**{k: g(k)[t][None] for k in ("ux", "uy", "uh", "ua", "tx", "ty", "th")})
+            obs, rew, _ = env.step(torch.from_numpy(g("actions")[t][None].astype(np.int32)))
+            np.testing.assert_allclose(rew[0].cpu().numpy(), g("reward")[t], rtol=0, atol=2e-5, err_msg=f"{name} t{t}")
+    # fused-call form: T steps == T single steps, bit for bit, including the episode accumulators
+    cfg = uavtrack.EnvConfig(n_envs=40, n_uav=20, m_targets=10, cooperative=0.3, x_max=600.0, y_max=600.0,
+                             reward_mode=uavtrack.RewardMode.PMI)
+    a, b = uavtrack.BatchedUavEnv(cfg), uavtrack.BatchedUavEnv(cfg)
+    a.set_pmi(pmi_state_dict); b.set_pmi(pmi_state_dict)
+    a.reset(seed=9); b.reset(seed=9)
+    act = torch.randint(0, 12, (6, 40, 20), dtype=torch.int32, device="cuda")
+    many = a.step_many(act)
+    ep = torch.zeros(40, 5, device="cuda")
+    for t in range(6):
+        obs, rew, _ = b.step(act[t])
+        assert torch.equal(rew, many["reward"][t]) and torch.equal(obs, many["obs"][t])
+        ep[:, 0] += rew.mean(1); ep[:, 1:4] += b.info["terms"].mean(2).T; ep[:, 4] += b.info["covered"]
+    torch.testing.assert_close(many["ep_sums"], ep, rtol=1e-5, atol=1e-5)
+    # and a PMI env without weights refuses to step
+    c = uavtrack.BatchedUavEnv(cfg); c.reset(seed=1)
+    with pytest.raises(RuntimeError, match="set_pmi_weights"):
+        c.step(act[0])
+
+
 def test_dense_box_many_neighbours(uavtrack):
     """Small box: every range test is busy (neighbour counts near N, many tracked targets,
     UAVs leaving the box)."""
