@@ -51,7 +51,9 @@ def parse():
     ap.add_argument("--n-uav", type=int, default=20)
     ap.add_argument("--m-targets", type=int, default=10)
     ap.add_argument("--dim", type=int, default=2)
-    ap.add_argument("--cooperative", type=float, default=0.0)
+    ap.add_argument("--reward", choices=["raw", "mean", "pmi"], default="raw",
+                    help="raw = MAAC (configs[1]), mean = MAAC-G, pmi = MAAC-R (configs[2])")
+    ap.add_argument("--pmi-hidden", type=int, default=128)
     ap.add_argument("--rollout", type=int, default=200, help="steps per fused launch (1 = one launch per step)")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -60,12 +62,37 @@ def parse():
     return ap.parse_args()
 
 
+def synthetic_pmi_state_dict(hidden, seed=42):
+    """Random-init PMINetwork-shaped weights (PMINet.py:29-38 shapes, torch default init ranges)
+    with non-trivial BatchNorm statistics; there is no checkpoint to load."""
+    import numpy as np
+    r = np.random.RandomState(seed)
+    sd = {}
+    for lin, bn, fan_in in (("fc_comm", "bn_comm", 5), ("fc_obs", "bn_obs", 4),
+                            ("fc_boundary_state", "bn_boundary_state", 3), ("fc1", "bn1", 3 * hidden)):
+        k = 1.0 / np.sqrt(fan_in)
+        sd[lin + ".weight"] = r.uniform(-k, k, (hidden, fan_in)).astype(np.float32)
+        sd[lin + ".bias"] = r.uniform(-k, k, hidden).astype(np.float32)
+        sd[bn + ".weight"] = r.uniform(0.5, 1.5, hidden).astype(np.float32)
+        sd[bn + ".bias"] = (r.randn(hidden) * 0.2).astype(np.float32)
+        sd[bn + ".running_mean"] = (r.randn(hidden) * 0.3).astype(np.float32)
+        sd[bn + ".running_var"] = r.uniform(0.5, 2.0, hidden).astype(np.float32)
+    k = 1.0 / np.sqrt(hidden)
+    sd["fc2.weight"] = r.uniform(-k, k, (1, hidden)).astype(np.float32)
+    sd["fc2.bias"] = r.uniform(-k, k, 1).astype(np.float32)
+    return sd
+
+
 def make_env(uavtrack, args, B, device, env_offset=0):
     nc = 3 if args.dim == 3 else 1
+    mode = {"raw": uavtrack.RewardMode.RAW, "mean": uavtrack.RewardMode.MEAN, "pmi": uavtrack.RewardMode.PMI}[args.reward]
     cfg = uavtrack.EnvConfig(n_envs=B, n_uav=args.n_uav, m_targets=args.m_targets, dim=args.dim, nc=nc,
-                             cooperative=args.cooperative, horizon=args.rollout if args.rollout > 1 else 200,
-                             env_offset=env_offset)
-    return uavtrack.BatchedUavEnv(cfg, device)
+                             cooperative=args.cooperative, reward_mode=mode,
+                             horizon=args.rollout if args.rollout > 1 else 200, env_offset=env_offset)
+    env = uavtrack.BatchedUavEnv(cfg, device)
+    if args.reward == "pmi":
+        env.set_pmi(synthetic_pmi_state_dict(args.pmi_hidden, 42))
+    return env
 
 
 def run_rollouts(env, actions, steps, rollout, out, events=None, gather=None):
@@ -110,6 +137,7 @@ def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, en
     if gather is not None:
         dist.barrier()
     events = []
+    pairs0 = env.pmi_pairs_scored() if args.reward == "pmi" else 0
     t0 = time.perf_counter()
     launches = run_rollouts(env, actions, steps, rollout, out, events=events, gather=gather)
     torch.cuda.synchronize(device)
@@ -118,8 +146,9 @@ def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, en
     wall = time.perf_counter() - t0
     kern_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in events)
     info = env.kernel_info()
+    pairs = env.pmi_pairs_scored() - pairs0 if args.reward == "pmi" else 0
     env.close()
-    return dict(wall_s=wall, kernel_ms_total=kern_ms, launches=launches, steps=steps, geometry=info)
+    return dict(wall_s=wall, kernel_ms_total=kern_ms, launches=launches, steps=steps, geometry=info, pmi_pairs=pairs)
 
 
 def host_cores():
@@ -148,9 +177,12 @@ def cpu_baseline(args, seconds):
 
     def run(B, T, threads):
         env = OracleEnv(OracleConfig(n_envs=B, n_uav=N, m_targets=M, cooperative=args.cooperative,
-                                     dim=2), n_threads=threads)
+                                     dim=args.dim, nc=3 if args.dim == 3 else 1), n_threads=threads)
+        if args.reward == "pmi":
+            from oracle import OraclePmi
+            env.pmi = OraclePmi.from_state_dict(synthetic_pmi_state_dict(args.pmi_hidden, 42))
         env.reset_philox(seed=args.seed)
-        act = np.random.RandomState(args.seed).randint(0, 12, size=(T, B, N)).astype(np.int32)
+        act = np.random.RandomState(args.seed).randint(0, 12 * (3 if args.dim == 3 else 1), size=(T, B, N)).astype(np.int32)
         t0 = time.perf_counter()
         for t in range(T):
             env.step(act[t])
@@ -170,6 +202,7 @@ def cpu_baseline(args, seconds):
 
 def main():
     args = parse()
+    args.cooperative = 0.0 if args.reward == "raw" else 0.3       # configs/MAAC.yaml vs MAAC-G/MAAC-R.yaml
     import torch
     import torch.distributed as dist
     import uavtrack
@@ -218,10 +251,13 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{B} envs x {N} UAVs x {M} targets per GPU, {args.dim}-D, "
-                            f"{'MAAC tracking reward' if args.cooperative == 0 else 'MAAC-G neighbour-mean reward'}"
-                            f" (BASELINE configs[{1 if world == 1 else 4}])",
+                            + {"raw": "MAAC tracking reward", "mean": "MAAC-G neighbour-mean reward",
+                               "pmi": f"MAAC-R reciprocal (PMI H={args.pmi_hidden}) reward"}[args.reward]
+                            + (f" (BASELINE configs[{4 if world > 1 else (3 if args.dim == 3 else {'raw': 1, 'mean': 1, 'pmi': 2}[args.reward])}])"),
                 "envs_total": world * B,
-                "launch": f"uavtrack_step_many, {args.rollout} steps per launch, reset between rollouts"
+                "launch": (f"uavtrack_step_many, {args.rollout} steps per call, reset between rollouts"
+                           + ("; MAAC-R issues 3 kernels per step (fused step, MFMA pair scorer, softmax mix)"
+                              if args.reward == "pmi" else " (one kernel launch per call)"))
                           if args.rollout > 1 else "uavtrack_step, one launch per step",
                 "actions": "pre-sampled int32[T,B,N] uniform, seed 42, resident in HBM",
                 "outputs": "obs[T,B,N,12] reward[T,B,N] terms[T,3,B,N] covered[T,B] done[T,B] ep_sums[B,5], all written",
@@ -244,17 +280,31 @@ def main():
                 "timing": "HIP events on the launch stream, around every rollout launch of the timed region",
             },
         }
+        if args.reward == "pmi":
+            H = args.pmi_hidden
+            flop_pair = 2.0 * (12 * H + 3 * H * H + H)               # 101 632 at H = 128
+            tf = res["pmi_pairs"] * flop_pair / (res["kernel_ms_total"] * 1e-3) / 1e12
+            line["roofline_hbm_all_kernels"] = line["roofline"]
+            line["roofline"] = {
+                "bound": "mfma", "kernel": "pmi_score_kernel", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s",
+                "frac": tf / 157.3, "traffic": None,
+                "flop_per_pair": flop_pair, "pairs_scored": res["pmi_pairs"],
+                "pairs_per_agent_step": res["pmi_pairs"] / (B * N * args.steps),
+                "timing": "HIP events around every uavtrack_step_many call of the timed region (all three kernels of "
+                          "each step: a lower bound for the scorer alone; the per-kernel split is in profiles/)",
+                "peak_note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak = fp32 vector peak, MI355X_MICROARCH.md",
+            }
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(traffic_file):
             try:
                 tr = json.load(open(traffic_file))
                 key = f"{B}x{N}x{M}_T{args.rollout}"
-                if key in tr:
+                if key in tr and args.reward == "raw" and args.dim == 2:
                     line["roofline"]["traffic"] = tr[key]["hbm_bytes_per_launch"]
                     line["roofline"]["traffic_source"] = tr[key].get("source", "profiles/")
             except Exception:
                 pass
-        if world == 1 and not args.no_extras:
+        if world == 1 and not args.no_extras and args.reward != "pmi":
             # the same kernel, one launch per env step (what a closed-loop policy would do eagerly)
             k = min(args.steps, 1000)
             r1 = time_config(uavtrack, args, B, k, min(args.warmup, 200), 1, device)

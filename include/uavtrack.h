@@ -146,6 +146,10 @@ int uavtrack_step_many(uavtrack_env *env, int32_t T, const int32_t *actions,
                        float *obs, float *reward, float *terms,
                        int32_t *covered, uint8_t *done, float *ep_sums, void *stream);
 
+/* MAAC-R accounting for reports: out[0] = neighbour pairs scored by the PMI network since
+ * the weights were set (each unordered pair once per step).  Synchronises `stream`. */
+int uavtrack_pmi_pairs_scored(uavtrack_env *env, uint64_t *out, void *stream);
+
 /* Launch geometry of the step kernel, for reports: out[0] = workgroup size,
  * out[1] = envs per workgroup, out[2] = workgroups, out[3] = LDS bytes per
  * workgroup, out[4] = 1 if a compile-time-specialised (N, M) variant is used. */

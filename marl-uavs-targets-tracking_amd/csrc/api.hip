@@ -10,6 +10,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 using namespace uavtrack;
 
@@ -44,7 +45,7 @@ void free_state(uavtrack_env *env)
 {
     StateBlock &s = env->state;
     void *ptrs[] = {s.ux, s.uy, s.uz, s.uh, s.ua, s.tx, s.ty, s.tz, s.th, s.step_count,
-                    env->d_state, env->pmi.blob, env->pairs, env->pair_count, env->scores, env->raw,
+                    env->d_state, env->pmi.blob, env->pairs, env->pair_count, env->pair_total, env->scores, env->raw,
                     env->obs_tmp, env->terms_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -280,9 +281,12 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
         env->pmi = PmiWeights();
         HIP_TRY(dmalloc(&env->pmi.blob, n_floats));
     }
-    // pageable host source: the copy is staged before this returns, so `folded` may be freed by the caller
-    HIP_TRY(hipMemcpyAsync(env->pmi.blob, folded, n_floats * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    {   // fc1 goes up in the scorer's register order; the copy has completed before `packed` dies
+        std::vector<float> packed(n_floats);
+        pack_pmi_blob(folded, packed.data(), hidden);
+        HIP_TRY(hipMemcpyAsync(env->pmi.blob, packed.data(), n_floats * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     env->pmi.hidden = hidden;
     env->pmi.n_floats = n_floats;
     if (!env->pairs) {   // MAAC-R scratch, sized for the worst case (every pair within dp)
@@ -291,6 +295,9 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
         const size_t max_pairs = (size_t)c.n_envs * c.n_uav * (c.n_uav - 1) / 2;
         HIP_TRY(dmalloc(&env->pairs, max_pairs));
         HIP_TRY(dmalloc(&env->pair_count, 1));
+        HIP_TRY(hipMemsetAsync(env->pair_count, 0, sizeof(unsigned), st));
+        HIP_TRY(dmalloc(&env->pair_total, 1));
+        HIP_TRY(hipMemsetAsync(env->pair_total, 0, sizeof(unsigned long long), st));
         HIP_TRY(dmalloc(&env->scores, BN * c.n_uav));
         HIP_TRY(dmalloc(&env->raw, BN));
         HIP_TRY(dmalloc(&env->obs_tmp, BN * UAVTRACK_OBS_DIM));
@@ -339,8 +346,7 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
         p.obs = obs_t; p.reward = reward_t; p.terms = terms_t;
         p.covered = covered_t;
         p.done = done ? done + (size_t)t * c.n_envs : nullptr;
-        HIP_TRY(hipMemsetAsync(env->pair_count, 0, sizeof(unsigned), st));
-        HIP_TRY(launch_rollout(env, p, st));
+        HIP_TRY(launch_rollout(env, p, st));   // pair_count is zero: set at allocation, re-zeroed by the finalize kernel
         HIP_TRY(launch_pmi_score(env, obs_t, st));
         HIP_TRY(launch_pmi_finalize(env, reward_t, terms_t, covered_t, ep_sums, st));
     }
@@ -357,6 +363,20 @@ int uavtrack_step_many(uavtrack_env *env, int32_t T, const int32_t *actions, flo
                        float *terms, int32_t *covered, uint8_t *done, float *ep_sums, void *stream)
 {
     return run_steps(env, T, actions, obs, reward, terms, covered, done, ep_sums, stream, "uavtrack_step_many");
+}
+
+int uavtrack_pmi_pairs_scored(uavtrack_env *env, uint64_t *out, void *stream)
+{
+    if (!env || !out) return fail("uavtrack_pmi_pairs_scored: null argument");
+    *out = 0;
+    if (!env->pair_total) return 0;
+    HIP_TRY(hipSetDevice(env->cfg.device_id));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, env->pair_total, sizeof v, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *out = v;
+    return 0;
 }
 
 int uavtrack_kernel_info(uavtrack_env *env, int64_t out[5])

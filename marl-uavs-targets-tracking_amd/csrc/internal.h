@@ -80,6 +80,7 @@ struct uavtrack_env {
     size_t pmi_scratch_bytes = 0;
     uint2 *pairs = nullptr;
     unsigned *pair_count = nullptr;
+    unsigned long long *pair_total = nullptr;
     float *scores = nullptr, *raw = nullptr, *obs_tmp = nullptr, *terms_tmp = nullptr;
 };
 
@@ -91,6 +92,7 @@ hipError_t launch_rollout(const uavtrack_env *env, const StepParams &p, hipStrea
 
 // pmi_kernel.hip
 bool pmi_hidden_supported(int hidden);
+void pack_pmi_blob(const float *abi_blob, float *device_order, int hidden);
 hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream_t stream);
 hipError_t launch_pmi_finalize(const uavtrack_env *env, float *reward, const float *terms, const int32_t *covered,
                                float *ep_sums, hipStream_t stream);

@@ -37,6 +37,7 @@ struct PmiParams {
     const uint2 *pairs;      // {flat agent index of i, j}
     const unsigned *pair_count;
     float *scores;           // [B][N][N]
+    unsigned long long *pair_total;
     int32_t N;
 };
 
@@ -63,28 +64,36 @@ __global__ void __launch_bounds__(H * 2) pmi_score_kernel(const PmiParams q)
     const int kh = lane >> 5;
 
     // ---- stationary operands
-    const float *W1 = q.blob + 15 * H;                     // [3H][H], input-major
+    // fc1 is stored on the device pre-packed in register order (pack_pmi_blob): per column block and
+    // group of four k-steps one float4 per lane, so the stationary slice arrives in KH/4 fully
+    // coalesced 1-KiB loads per wavefront instead of KH strided dword loads.
+    const float *W1 = q.blob + 15 * H;
     const float *b1 = W1 + (size_t)K * H;
     const float *w2 = b1 + H;
     const float b2 = w2[H];
     float breg[KH];
+    const float4 *wp = reinterpret_cast<const float4 *>(W1) + (size_t)w * (KH / 4) * 64 + lane;
 #pragma unroll
-    for (int t = 0; t < KH; ++t) breg[t] = W1[(size_t)(2 * t + kh) * H + col];   // B[k = 2t + kh][col]
+    for (int t4 = 0; t4 < KH / 4; ++t4) {                  // breg[t] = B[k = 2t + kh][col]
+        const float4 v = wp[t4 * 64];
+        breg[4 * t4 + 0] = v.x; breg[4 * t4 + 1] = v.y; breg[4 * t4 + 2] = v.z; breg[4 * t4 + 3] = v.w;
+    }
     const float bias1 = b1[col], wout = w2[col];
     for (int k = tid; k < 15 * H; k += NT) wa[k] = q.blob[k];
     __syncthreads();
 
     const unsigned npairs = *q.pair_count;
     const unsigned ntiles = (npairs + 31) >> 5;
+    if (blockIdx.x == 0 && tid == 0) *q.pair_total += npairs;      // accounting only (one writer)
     const int p = tid & 31;              // pair of this thread in the branch layers
     const int grp = tid >> 5;            // which slice of the H outputs of each branch
 
-    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        // ---- gather + branch layers (PMINet.py:50-55), x = la_i * la_j (uav.py:281)
+    // gather of one tile: pair record + x = la_i * la_j (uav.py:281).  Issued one tile ahead so that
+    // the loads fly under the previous tile's MFMA phase.
+    auto gather = [&](unsigned tile, uint2 &pr, float (&x)[12]) {
         const unsigned pi = tile * 32 + p;
-        float x[12];
-        uint2 pr = make_uint2(0, 0);
-        if (pi < npairs) {
+        pr = make_uint2(0, 0);
+        if (tile < ntiles && pi < npairs) {
             pr = q.pairs[pi];
             const unsigned gi = pr.x, gj = (pr.x / q.N) * q.N + pr.y;
             const float4 *oi = reinterpret_cast<const float4 *>(q.obs + (size_t)gi * 12);
@@ -99,6 +108,18 @@ __global__ void __launch_bounds__(H * 2) pmi_score_kernel(const PmiParams q)
 #pragma unroll
             for (int v = 0; v < 12; ++v) x[v] = 0.0f;
         }
+    };
+
+    uint2 pr_next;
+    float x_next[12];
+    gather(blockIdx.x, pr_next, x_next);
+
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // ---- branch layers (PMINet.py:50-55) on the prefetched inputs
+        const uint2 pr = pr_next;
+        float x[12];
+#pragma unroll
+        for (int v = 0; v < 12; ++v) x[v] = x_next[v];
 #pragma unroll
         for (int m = 0; m < PER; ++m) {
             const int o = grp + GROUPS * m;                 // output index within a branch, 0..H-1
@@ -118,6 +139,7 @@ __global__ void __launch_bounds__(H * 2) pmi_score_kernel(const PmiParams q)
             h0s[((k2 & 1) * 32 + p) * ROW + (k2 >> 1)] = fmaxf(bs, 0.0f);
         }
         __syncthreads();
+        gather(tile + gridDim.x, pr_next, x_next);          // next tile's loads overlap this tile's MFMAs
 
         // ---- fc1 (+ folded bn1) on the matrix cores: [32 pairs x 3H] x [3H x 32 cols]
         f32x16 acc;
@@ -152,7 +174,8 @@ __global__ void __launch_bounds__(H * 2) pmi_score_kernel(const PmiParams q)
             q.scores[(size_t)gi * q.N + jj] = sc;
             q.scores[((size_t)bidx * q.N + jj) * q.N + ii] = sc;
         }
-        __syncthreads();   // h0s / part are rewritten by the next tile
+        // no third barrier: the next tile writes h0s (everyone is past the MFMA reads) and rewrites
+        // `part` only after its own first barrier, which the readers above reach first
     }
 }
 
@@ -160,76 +183,121 @@ struct FinalizeParams {
     const float *ux, *uy, *uz;
     const float *raw, *scores;
     float *reward;
-    int32_t B, N, three_d;
+    const float *terms;          // [3][B][N] of this step (nullable)
+    const int32_t *covered;      // [B] of this step (nullable)
+    float *ep_sums;              // [B][5] running episode accumulators (nullable)
+    unsigned *pair_count;        // reset here for the next step's pair emission
+    int32_t B, N, E, three_d;
     float dp2, coop;
 };
 
-__global__ void __launch_bounds__(256) pmi_finalize_kernel(const FinalizeParams f)
+// One lane per UAV, E whole environments per workgroup (same geometry as the step kernel).
+// Poses and raw rewards of the workgroup's environments are staged in LDS; every lane walks
+// its row of the score matrix with unconditional, independent loads.
+__global__ void __launch_bounds__(kMaxWorkgroup) pmi_finalize_kernel(const FinalizeParams f)
 {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long long)f.B * f.N) return;
-    const int b = (int)(gid / f.N), i = (int)(gid - (long long)b * f.N);
-    const size_t e0 = (size_t)b * f.N;
-    const float x = f.ux[gid], y = f.uy[gid], z = f.three_d ? f.uz[gid] : 0.0f;
-    const float raw_i = f.raw[gid];
-    const float *srow = f.scores + (size_t)gid * f.N;
-    // pass 1: max score over neighbours (same d2 expression as the pair emission in the step kernel)
-    float mx = -INFINITY;
-    int cnt = 0;
-    for (int j = 0; j < f.N; ++j) {
-        const v2f dd = (v2f){f.ux[e0 + j], f.uy[e0 + j]} - (v2f){x, y};
-        const v2f sq = dd * dd;
-        float d2 = sq.x + sq.y;
-        if (f.three_d) { const float dz = f.uz[e0 + j] - z; d2 = fmaf(dz, dz, d2); }
-        if (j != i && d2 <= f.dp2) { mx = fmaxf(mx, srow[j]); ++cnt; }
+    extern __shared__ float4 fin4[];
+    float4 *pose = fin4;                                        // [E*N] (x, y, z, raw)
+    float *red = reinterpret_cast<float *>(fin4 + f.E * f.N);   // [E*N][4] reward + 3 terms, for ep_sums
+    const int tid = threadIdx.x;
+    const int N = f.N;
+    const int env0 = blockIdx.x * f.E;
+    const int envs_here = min(f.E, f.B - env0);
+    const int e = tid / N, i = tid - e * N;
+    const bool active = tid < f.E * N && e < envs_here;
+    const size_t gid = (size_t)(env0 + e) * N + i;
+    if (blockIdx.x == 0 && tid == 0) *f.pair_count = 0;
+    float x = 0, y = 0, z = 0, raw_i = 0;
+    if (active) {
+        x = f.ux[gid]; y = f.uy[gid]; raw_i = f.raw[gid];
+        if (f.three_d) z = f.uz[gid];
+        pose[tid] = make_float4(x, y, z, raw_i);
     }
-    float r = (1.0f - f.coop) * raw_i;                               // uav.py:290
-    if (cnt) {
-        float den = 0.0f, num = 0.0f;
-        for (int j = 0; j < f.N; ++j) {
-            const v2f dd = (v2f){f.ux[e0 + j], f.uy[e0 + j]} - (v2f){x, y};
+    __syncthreads();
+    float r = 0;
+    if (active) {
+        const float *srow = f.scores + gid * N;
+        const float4 *pe = pose + e * N;
+        // pass 1: max score over neighbours (same d2 expression as the pair emission in the step kernel)
+        float mx = -INFINITY;
+        int cnt = 0;
+        for (int j = 0; j < N; ++j) {
+            const float4 pj = pe[j];
+            const float sj = srow[j];
+            const v2f dd = (v2f){pj.x, pj.y} - (v2f){x, y};
             const v2f sq = dd * dd;
             float d2 = sq.x + sq.y;
-            if (f.three_d) { const float dz = f.uz[e0 + j] - z; d2 = fmaf(dz, dz, d2); }
-            if (j != i && d2 <= f.dp2) {
-                const float ew = expf(srow[j] - mx);
-                den += ew;
-                num = fmaf(ew, f.raw[e0 + j], num);
-            }
+            if (f.three_d) { const float dz = pj.z - z; d2 = fmaf(dz, dz, d2); }
+            const bool nb = j != i && d2 <= f.dp2;
+            mx = nb ? fmaxf(mx, sj) : mx;
+            cnt += nb ? 1 : 0;
         }
-        r = fmaf(f.coop, num / den, r);                              // uav.py:288
+        r = (1.0f - f.coop) * raw_i;                                 // uav.py:290
+        if (cnt) {
+            float den = 0.0f, num = 0.0f;
+            for (int j = 0; j < N; ++j) {
+                const float4 pj = pe[j];
+                const float sj = srow[j];
+                const v2f dd = (v2f){pj.x, pj.y} - (v2f){x, y};
+                const v2f sq = dd * dd;
+                float d2 = sq.x + sq.y;
+                if (f.three_d) { const float dz = pj.z - z; d2 = fmaf(dz, dz, d2); }
+                if (j != i && d2 <= f.dp2) {                         // scipy softmax, uav.py:287
+                    const float ew = expf(sj - mx);
+                    den += ew;
+                    num = fmaf(ew, pj.w, num);
+                }
+            }
+            r = fmaf(f.coop, num / den, r);                          // uav.py:288
+        }
+        r = fminf(fmaxf(r, -1.0f), 1.0f);                            // environment.py:225
+        f.reward[gid] = r;
     }
-    f.reward[gid] = fminf(fmaxf(r, -1.0f), 1.0f);                    // environment.py:225
-}
-
-// train.py:181-192 accumulators for the MAAC-R path (the fused kernel does this in-register)
-struct EpParams {
-    const float *reward, *terms;
-    const int32_t *covered;
-    float *ep_sums;
-    int32_t B, N;
-};
-
-__global__ void __launch_bounds__(256) ep_accumulate_kernel(const EpParams q)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= q.B) return;
-    const size_t BN = (size_t)q.B * q.N;
-    float s[4] = {0, 0, 0, 0};
-    for (int i = 0; i < q.N; ++i) {
-        const size_t g = (size_t)b * q.N + i;
-        s[0] += q.reward[g];
-        if (q.terms) { s[1] += q.terms[g]; s[2] += q.terms[BN + g]; s[3] += q.terms[2 * BN + g]; }
+    if (f.ep_sums) {                                                 // train.py:181-192 accumulators
+        const size_t BN = (size_t)f.B * N;
+        if (active) {
+            red[tid * 4 + 0] = r;
+            red[tid * 4 + 1] = f.terms ? f.terms[gid] : 0.0f;
+            red[tid * 4 + 2] = f.terms ? f.terms[BN + gid] : 0.0f;
+            red[tid * 4 + 3] = f.terms ? f.terms[2 * BN + gid] : 0.0f;
+        }
+        __syncthreads();
+        if (active && i == 0) {
+            float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            for (int j = 0; j < N; ++j) {                            // fixed order
+                const float *q = red + (e * N + j) * 4;
+                s0 += q[0]; s1 += q[1]; s2 += q[2]; s3 += q[3];
+            }
+            const float inv = 1.0f / (float)N;
+            float *ep = f.ep_sums + (size_t)(env0 + e) * 5;
+            ep[0] += s0 * inv; ep[1] += s1 * inv; ep[2] += s2 * inv; ep[3] += s3 * inv;
+            if (f.covered) ep[4] += (float)f.covered[env0 + e];
+        }
     }
-    const float inv = 1.0f / (float)q.N;
-    float *ep = q.ep_sums + (size_t)b * 5;
-    ep[0] += s[0] * inv; ep[1] += s[1] * inv; ep[2] += s[2] * inv; ep[3] += s[3] * inv;
-    if (q.covered) ep[4] += (float)q.covered[b];
 }
 
 }  // namespace
 
 bool pmi_hidden_supported(int hidden) { return hidden == 64 || hidden == 128; }
+
+// Host-side repack of the fc1 block of the ABI blob (W1[3H][H], input-major) into the order the
+// scorer's lanes load it: [column block w][k-step group t4][lane][4], element q of lane l being
+// W1[2 (4 t4 + q) + (l >> 5)][32 w + (l & 31)].
+void pack_pmi_blob(const float *abi_blob, float *device_order, int H)
+{
+    const int K = 3 * H, KH = K / 2, NW = H / 32;
+    const size_t w1_off = (size_t)15 * H, w1_len = (size_t)K * H;
+    const size_t total = w1_off + w1_len + H + H + 1;
+    for (size_t k = 0; k < total; ++k) device_order[k] = abi_blob[k];
+    const float *W1 = abi_blob + w1_off;
+    float *dst = device_order + w1_off;
+    for (int w = 0; w < NW; ++w)
+        for (int t4 = 0; t4 < KH / 4; ++t4)
+            for (int l = 0; l < 64; ++l)
+                for (int q = 0; q < 4; ++q)
+                    dst[(((size_t)w * (KH / 4) + t4) * 64 + l) * 4 + q] =
+                        W1[(size_t)(2 * (4 * t4 + q) + (l >> 5)) * H + w * 32 + (l & 31)];
+}
 
 hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream_t stream)
 {
@@ -239,6 +307,7 @@ hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream
     q.pairs = env->pairs;
     q.pair_count = env->pair_count;
     q.scores = env->scores;
+    q.pair_total = env->pair_total;
     q.N = env->cfg.n_uav;
     // persistent workgroups grid-striding over 32-pair tiles: one per CU at H = 128 (288 registers per
     // lane leave room for one wavefront per SIMD), two at H = 64
@@ -259,14 +328,12 @@ hipError_t launch_pmi_finalize(const uavtrack_env *env, float *reward, const flo
     FinalizeParams f;
     f.ux = env->state.ux; f.uy = env->state.uy; f.uz = env->state.uz;
     f.raw = env->raw; f.scores = env->scores; f.reward = reward;
-    f.B = c.n_envs; f.N = c.n_uav; f.three_d = c.dim == 3;
+    f.terms = terms; f.covered = covered; f.ep_sums = ep_sums;
+    f.pair_count = env->pair_count;
+    f.B = c.n_envs; f.N = c.n_uav; f.E = env->geo.envs_per_wg; f.three_d = c.dim == 3;
     f.dp2 = env->base.dp2; f.coop = env->base.coop;
-    const long long total = (long long)c.n_envs * c.n_uav;
-    hipLaunchKernelGGL(pmi_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, f);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess || !ep_sums) return e;
-    EpParams q{reward, terms, covered, ep_sums, c.n_envs, c.n_uav};
-    hipLaunchKernelGGL(ep_accumulate_kernel, dim3((unsigned)((c.n_envs + 255) / 256)), dim3(256), 0, stream, q);
+    const size_t lds = (size_t)f.E * f.N * (16 + 16);
+    hipLaunchKernelGGL(pmi_finalize_kernel, dim3(env->geo.groups), dim3(env->geo.wgs), lds, stream, f);
     return hipGetLastError();
 }
 

@@ -174,6 +174,12 @@ class BatchedUavEnv:
         _lib.check(self._lib.uavtrack_set_pmi_weights(self._h, C.c_void_p(blob.ctypes.data), blob.size, hidden,
                                                       self._stream()), "uavtrack_set_pmi_weights")
 
+    def pmi_pairs_scored(self) -> int:
+        """Neighbour pairs the PMI network has scored so far (synchronises the stream)."""
+        out = C.c_uint64(0)
+        _lib.check(self._lib.uavtrack_pmi_pairs_scored(self._h, C.byref(out), self._stream()), "pmi_pairs_scored")
+        return int(out.value)
+
     @property
     def reward_mode(self) -> RewardMode:
         return self.cfg.resolved_mode()
