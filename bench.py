@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip per-step-launch and saturating-batch legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only to rehearse "
+                    "the multi-rank code path on a single GPU together with UAVTRACK_BENCH_ONE_GPU=1")
     return ap.parse_args()
 
 
@@ -210,10 +212,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("UAVTRACK_BENCH_ONE_GPU") == "1":
+        local_rank = 0                      # rehearsal: every rank shares cuda:0 (gloo backend only)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the environment has no CPU path")
@@ -223,7 +230,7 @@ def main():
     B, N, M = args.envs, args.n_uav, args.m_targets
     res = time_config(uavtrack, args, B, args.steps, args.warmup, args.rollout, device,
                       dist=dist if world > 1 else None, env_offset=rank * B, total_envs=world * B)
-    wall = torch.tensor([res["wall_s"]], dtype=torch.float64, device=device)
+    wall = torch.tensor([res["wall_s"]], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(wall, op=dist.ReduceOp.MAX)
     wall_s = float(wall.item())
@@ -261,7 +268,8 @@ def main():
                           if args.rollout > 1 else "uavtrack_step, one launch per step",
                 "actions": "pre-sampled int32[T,B,N] uniform, seed 42, resident in HBM",
                 "outputs": "obs[T,B,N,12] reward[T,B,N] terms[T,3,B,N] covered[T,B] done[T,B] ep_sums[B,5], all written",
-                "parallelism": f"env-sharded x{world}, RCCL all-gather of ep_sums per rollout" if world > 1 else "1 GPU",
+                "parallelism": (f"env-sharded x{world}, {'RCCL' if args.backend == 'nccl' else args.backend} "
+                                f"all-gather of ep_sums per rollout") if world > 1 else "1 GPU",
                 "geometry": res["geometry"],
             },
             "roofline": {

@@ -37,8 +37,12 @@ def gather_rollout_summary(ep_sums, n_envs_total: Optional[int] = None, group=No
     if b_local != b_max:
         send = torch.zeros((b_max,) + tuple(ep_sums.shape[1:]), dtype=ep_sums.dtype, device=ep_sums.device)
         send[:b_local] = ep_sums
-    out = torch.empty((world * b_max,) + tuple(ep_sums.shape[1:]), dtype=ep_sums.dtype, device=ep_sums.device)
+    dev = ep_sums.device
+    if dev.type == "cuda" and dist.get_backend(group) == "gloo":
+        send = send.cpu()          # rehearsal / debugging on gloo: stage through the host
+    out = torch.empty((world * b_max,) + tuple(ep_sums.shape[1:]), dtype=ep_sums.dtype, device=send.device)
     dist.all_gather_into_tensor(out, send.contiguous(), group=group)
+    out = out.to(dev)
     if n_envs_total == world * b_max:
         return out
     parts = []
