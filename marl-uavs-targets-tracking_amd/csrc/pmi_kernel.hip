@@ -224,9 +224,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) pmi_finalize_kernel(const Final
         for (int j = 0; j < N; ++j) {
             const float4 pj = pe[j];
             const float sj = srow[j];
-            const v2f dd = (v2f){pj.x, pj.y} - (v2f){x, y};
-            const v2f sq = dd * dd;
-            float d2 = sq.x + sq.y;
+            float d2 = fmaf(pj.y - y, pj.y - y, (pj.x - x) * (pj.x - x));    // dist2() of step_kernel.hip
             if (f.three_d) { const float dz = pj.z - z; d2 = fmaf(dz, dz, d2); }
             const bool nb = j != i && d2 <= f.dp2;
             mx = nb ? fmaxf(mx, sj) : mx;
@@ -238,9 +236,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) pmi_finalize_kernel(const Final
             for (int j = 0; j < N; ++j) {
                 const float4 pj = pe[j];
                 const float sj = srow[j];
-                const v2f dd = (v2f){pj.x, pj.y} - (v2f){x, y};
-                const v2f sq = dd * dd;
-                float d2 = sq.x + sq.y;
+                float d2 = fmaf(pj.y - y, pj.y - y, (pj.x - x) * (pj.x - x));
                 if (f.three_d) { const float dz = pj.z - z; d2 = fmaf(dz, dz, d2); }
                 if (j != i && d2 <= f.dp2) {                         // scipy softmax, uav.py:287
                     const float ew = expf(sj - mx);

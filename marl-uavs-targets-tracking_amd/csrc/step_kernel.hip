@@ -14,25 +14,32 @@
 //
 // Mapping.  One lane per (env, uav).  A workgroup owns E = floor(WGS / N) whole
 // environments, so an environment never spans workgroups and the only
-// synchronisation is the workgroup barrier.  Per environment the workgroup keeps in
-// LDS: the UAV pose table in two interleaved copies (this step's post-move pose and
-// the previous one -- the reference moves UAVs one after the other, so UAV i sees
-// peers j < i after their move and peers j > i before it), the matching action
-// table, and the target table.  Lanes of one environment read the same table row in
-// the pair sweeps, which the LDS serves as a broadcast.  Pose, heading sin/cos and
-// action of the lane's own UAV live in registers across the T steps; HBM sees the
-// state once per launch and, per step, only the action read and the output writes.
+// synchronisation is the workgroup barrier.  Pose, heading sin/cos and action of the
+// lane's own UAV live in registers across the T steps; HBM sees the state once per
+// launch and, per step, only the action read and the output writes.
 //
-// No MFMA: there is no dense contraction on this path.  The bound is HBM for the
-// outputs (48 B of observation per agent-step) against ~1e3 VALU lane-ops per
-// agent-step for the all-pairs sweeps.
+// LDS tables are laid out for packed fp32 (v_pk_add/mul/fma_f32 do two values per lane
+// in one 4-cycle VALU slot, and the kernel is VALU-issue-bound): agents are stored in
+// PAIRS, structure-of-arrays inside the pair --
+//   UAV pair row    (x0,x1,y0,y1) (cos0,cos1,sin0,sin1) (a0,a1,z0,z1)    48 B
+//   target pair row (x0,x1,y0,y1) (cos0,cos1,sin0,sin1)                  32 B
+// so one packed instruction handles the same quantity of two peers.  The UAV table has
+// two copies per pair (this step's post-move poses and the previous step's): the
+// reference moves UAVs one after the other (environment.py:133-138), so UAV i sees peers
+// j < i after their move and peers j > i before it.  Lane i picks the copy per PAIR with
+// one address select (post-move iff 2*jp < i); the one pair that holds i itself then
+// contains a known self term (own post-move pose for odd i, own pre-move pose for even
+// i), which is subtracted after the sweep instead of testing j != i per pair.  Lanes of
+// one environment read the same row, which the LDS serves as a broadcast.
+//
+// No MFMA: there is no dense contraction on this path.
 
 #include "internal.h"
 
 #include <cstdlib>
 
-// Partial unrolling of the pair sweeps: full unrolling lets the scheduler hoist every
-// LDS table read of the environment into registers (256 VGPRs + scratch spills).
+// Partial unrolling of the pair sweeps (in agent pairs): full unrolling lets the scheduler
+// hoist every LDS table read of the environment into registers (256 VGPRs + scratch).
 #ifndef UAVTRACK_UNROLL_U
 #define UAVTRACK_UNROLL_U 5
 #endif
@@ -44,6 +51,8 @@ namespace uavtrack {
 
 namespace {
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 struct Acc {
     // peers (uav.py:124-147 rows, folded into sums)
     float cntU, iwU, sxU, syU, scU, ssU, saU;
@@ -53,9 +62,17 @@ struct Acc {
     float dup;   // uav.py:214-229
 };
 
+constexpr float kFar = 1.0e18f;   // padding agent of an odd-sized pair: every range test fails, 0 * kFar = 0
+
 __device__ __forceinline__ float fast_sqrt(float v) { return __builtin_amdgcn_sqrtf(v); }
 __device__ __forceinline__ float fast_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
 __device__ __forceinline__ float fast_exp2(float v) { return __builtin_amdgcn_exp2f(v); }
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat(float v) { return (v2f){v, v}; }
+
+// The squared distance every range test of the path uses (also in pmi_kernel.hip): dx*dx
+// rounded, then one fma.  Scalar and packed forms give identical bits.
+__device__ __forceinline__ float dist2(float dx, float dy) { return fmaf(dy, dy, dx * dx); }
 
 // Workgroups are dealt round-robin over the 8 XCDs; give consecutive environment
 // groups to one XCD so neighbouring output spans land in the same L2 (speed only).
@@ -88,10 +105,6 @@ __device__ __forceinline__ float wrap_heading(float h)
     return h;
 }
 
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-
 // sin/cos for |h| <= pi (headings are kept wrapped): quadrant reduction with a two-term
 // pi/2 and the Cephes single-precision minimax polynomials on [-pi/4, pi/4] (|err| ~ 1e-7).
 // ocml's sincosf carries a large-argument (Payne-Hanek) path the kernel never needs inside
@@ -118,123 +131,153 @@ __device__ __forceinline__ void sincos_any(float h, float *s, float *c)
     else sincosf(h, s, c);
 }
 
+// ---- LDS table geometry (float4 units) --------------------------------------------------
+__device__ __host__ __forceinline__ int pairs_of(int n) { return (n + 1) >> 1; }
+// env stride of the UAV table: pairs * 2 copies * 3 float4, plus one float4 when the stride would
+// be a multiple of 64 dwords (rows of different envs read by one lane group would share banks)
+__device__ __host__ __forceinline__ int ustride_of(int n)
+{
+    const int s = pairs_of(n) * 6;
+    return (s * 4) % 64 == 0 ? s + 1 : s;
+}
+__device__ __host__ __forceinline__ int tstride_of(int m)
+{
+    const int s = pairs_of(m) * 2;
+    return (s * 4) % 64 == 0 ? s + 1 : s;
+}
+
+// scalar views of the pair rows (slow paths, table fills)
+struct UavRow { float x, y, c, s, a, z; };
+__device__ __forceinline__ UavRow uav_elem(const float4 *rows, int j)   // rows: env base + copy * 3
+{
+    const float *f = reinterpret_cast<const float *>(rows + (j >> 1) * 6);
+    const int b = j & 1;
+    return UavRow{f[b], f[2 + b], f[4 + b], f[6 + b], f[8 + b], f[10 + b]};
+}
+__device__ __forceinline__ void uav_store(float4 *rows, int j, float x, float y, float c, float s, float a, float z)
+{
+    float *f = reinterpret_cast<float *>(rows + (j >> 1) * 6);
+    const int b = j & 1;
+    f[b] = x; f[2 + b] = y; f[4 + b] = c; f[6 + b] = s; f[8 + b] = a; f[10 + b] = z;
+}
+
 // ---------------------------------------------------------------------------------------
-// Pair sweeps of one UAV, fast path: packed fp32 (v_pk_*) on (x, y) / (cos, sin) pairs,
-// no per-pair `j != i` test.  The j == i iteration adds a known self term (distance 0 on
-// the post-move table, own pre-move pose on the sequential table); the accumulators start
-// at minus that term.  The uav.py:165/179 weight is 1 here (see sweep_weighted).
+// Pair sweeps of one UAV, fast path: two agents per packed instruction, no per-agent
+// `j != i` test (self terms are subtracted afterwards).  The uav.py:165/179 weight is 1
+// here (see sweep_weighted).
 template <int N_, int M_, bool Z3>
-__device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, int ebaseT, int i,
+__device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, int i,
                                            const float4 *__restrict__ rowNew, const float4 *__restrict__ rowOld,
-                                           const float4 *__restrict__ ttab,
-                                           const float *__restrict__ tzt, unsigned *__restrict__ covw, int covbase,
+                                           const float4 *__restrict__ trow, const v2f *__restrict__ tzrow,
+                                           unsigned *__restrict__ covw, int covbase,
                                            float xi, float yi, float zi, float ci, float si, float ai,
                                            float xo, float yo, float zo, float co, float so, float ao, Acc &a)
 {
-    const v2f pos = {xi, yi};
+    const v2f xi2 = splat(xi), yi2 = splat(yi), zi2 = splat(zi);
+    const int NP = pairs_of(N_ > 0 ? N_ : N), MP = pairs_of(M_ > 0 ? M_ : M);
 
     // ---- targets: observe_target (<= dp), tracking reward (<= dp), coverage (< dp)
-    v2f sxyT = {0.f, 0.f}, scsT = {0.f, 0.f};
-    float cntT = 0.f, trk = 0.f;
+    v2f sx = splat(0.f), sy = splat(0.f), sc = splat(0.f), ss = splat(0.f), cnt = splat(0.f), trk = splat(0.f);
     unsigned bits = 0;
 #pragma unroll UAVTRACK_UNROLL_T
-    for (int k = 0; k < (M_ > 0 ? M_ : M); ++k) {
-        const float4 tg = ttab[ebaseT + k];
-        const v2f d = (v2f){tg.x, tg.y} - pos;
-        const v2f sq = d * d;
-        float d2 = sq.x + sq.y;
-        if (Z3) {
-            const float dz = tzt[ebaseT + k] - zi;
-            d2 = fmaf(dz, dz, d2);
-        }
-        const float dist = fast_sqrt(d2);
-        const bool in = d2 <= p.dp2;
-        const float m = in ? 1.0f : 0.0f;
-        const v2f mm = {m, m};
-        sxyT = pk_fma(mm, d, sxyT);
-        scsT = pk_fma(mm, (v2f){tg.z, tg.w}, scsT);
-        cntT += m;
-        trk = fmaf(m, fmaf(-dist, p.inv_dp, 2.0f), trk);   // 1 + (dp - d)/dp
-        bits |= (d2 < p.dp2) ? (1u << (k & 31)) : 0u;
-        if ((k & 31) == 31 || k == (M_ > 0 ? M_ : M) - 1) {
+    for (int kp = 0; kp < MP; ++kp) {
+        const float4 q0 = trow[kp * 2], q1 = trow[kp * 2 + 1];
+        const v2f dx = (v2f){q0.x, q0.y} - xi2, dy = (v2f){q0.z, q0.w} - yi2;
+        v2f d2 = pk_fma(dy, dy, dx * dx);
+        if (Z3) { const v2f dz = tzrow[kp] - zi2; d2 = pk_fma(dz, dz, d2); }
+        const v2f dist = {fast_sqrt(d2.x), fast_sqrt(d2.y)};
+        const v2f mm = {d2.x <= p.dp2 ? 1.0f : 0.0f, d2.y <= p.dp2 ? 1.0f : 0.0f};
+        sx = pk_fma(mm, dx, sx);
+        sy = pk_fma(mm, dy, sy);
+        sc = pk_fma(mm, (v2f){q1.x, q1.y}, sc);
+        ss = pk_fma(mm, (v2f){q1.z, q1.w}, ss);
+        cnt += mm;
+        trk = pk_fma(mm, pk_fma(dist, splat(-p.inv_dp), splat(2.0f)), trk);   // 1 + (dp - d)/dp
+        const int k = 2 * kp;
+        bits |= (d2.x < p.dp2 ? (1u << (k & 31)) : 0u) | (d2.y < p.dp2 ? (2u << (k & 31)) : 0u);
+        if ((k & 31) == 30 || kp == MP - 1) {
             if (bits) atomicOr(&covw[covbase + (k >> 5)], bits);
             bits = 0;
         }
     }
+    a.cntT = cnt.x + cnt.y; a.iwT = a.cntT;
+    a.sxT = sx.x + sx.y; a.syT = sy.x + sy.y; a.trk = trk.x + trk.y;
+    // sum_k m (c_k r - c_i) = r sum_k m c_k - c_i cnt  (r = target speed / uav speed, uav.py:116)
+    a.scT = fmaf(sc.x + sc.y, p.vratio, -ci * a.cntT);
+    a.ssT = fmaf(ss.x + ss.y, p.vratio, -si * a.cntT);
 
-    // ---- peers.  Self terms first.
-    const float dup_self = fast_exp2(p.exp_k0);            // exp2(k0 - k1 * 0), as the loop computes it
-    const v2f dself = (v2f){xo, yo} - pos;
-    const v2f sqs = dself * dself;
-    float d2self = sqs.x + sqs.y;
-    if (Z3) d2self = fmaf(zo - zi, zo - zi, d2self);
-    const float mself = (d2self <= p.dc2) ? 1.0f : 0.0f;   // own pre-move pose, seen at j == i
-    const v2f nself = {-mself, -mself};
-    v2f sxyU = nself * dself, scsU = nself * (v2f){co, so}, sacU = nself * (v2f){ao, 1.0f};
-    float dup = -dup_self;
+    // ---- peers: duplicate punishment on post-move poses (<= 2dp), observe_uav on the
+    //      sequential view (<= dc)
+    sx = splat(0.f); sy = splat(0.f); sc = splat(0.f); ss = splat(0.f); cnt = splat(0.f);
+    v2f sa = splat(0.f), dup = splat(0.f);
 #pragma unroll UAVTRACK_UNROLL_U
-    for (int j = 0; j < (N_ > 0 ? N_ : N); ++j) {
-        const float4 *rs = (j < i) ? rowNew : rowOld;       // one select serves pose, action and z
-        const float4 nw = rowNew[j * 4];
-        const float4 mx = rs[j * 4];
-        const float4 ax = rs[j * 4 + 1];                    // (action, 1, z, -)
-        const v2f am = {ax.x, ax.y};
-        const v2f dn = (v2f){nw.x, nw.y} - pos;
-        const v2f dm = (v2f){mx.x, mx.y} - pos;
-        const v2f sqn = dn * dn, sqm = dm * dm;
-        float d2n = sqn.x + sqn.y, d2m = sqm.x + sqm.y;
+    for (int jp = 0; jp < NP; ++jp) {
+        const float4 *rs = (2 * jp < i) ? rowNew : rowOld;   // one select serves pose, heading, action, z
+        const float4 n0 = rowNew[jp * 6];
+        const float4 m0 = rs[jp * 6], m1 = rs[jp * 6 + 1], m2 = rs[jp * 6 + 2];
+        const v2f dxn = (v2f){n0.x, n0.y} - xi2, dyn = (v2f){n0.z, n0.w} - yi2;
+        const v2f dxm = (v2f){m0.x, m0.y} - xi2, dym = (v2f){m0.z, m0.w} - yi2;
+        v2f d2n = pk_fma(dyn, dyn, dxn * dxn), d2m = pk_fma(dym, dym, dxm * dxm);
         if (Z3) {
-            const float dzn = rowNew[j * 4 + 1].z - zi, dzm = ax.z - zi;
-            d2n = fmaf(dzn, dzn, d2n);
-            d2m = fmaf(dzm, dzm, d2m);
+            const float4 n2 = rowNew[jp * 6 + 2];
+            const v2f dzn = (v2f){n2.z, n2.w} - zi2, dzm = (v2f){m2.z, m2.w} - zi2;
+            d2n = pk_fma(dzn, dzn, d2n);
+            d2m = pk_fma(dzm, dzm, d2m);
         }
-        const float ex = fast_exp2(fmaf(fast_sqrt(d2n), -p.exp_k1, p.exp_k0));
-        dup += (d2n <= p.two_dp2) ? ex : 0.0f;
-        const float m = (d2m <= p.dc2) ? 1.0f : 0.0f;
-        const v2f mm = {m, m};
-        sxyU = pk_fma(mm, dm, sxyU);
-        scsU = pk_fma(mm, (v2f){mx.z, mx.w}, scsU);
-        sacU = pk_fma(mm, am, sacU);
+        const v2f w = pk_fma((v2f){fast_sqrt(d2n.x), fast_sqrt(d2n.y)}, splat(-p.exp_k1), splat(p.exp_k0));
+        dup += (v2f){d2n.x <= p.two_dp2 ? fast_exp2(w.x) : 0.0f, d2n.y <= p.two_dp2 ? fast_exp2(w.y) : 0.0f};
+        const v2f mm = {d2m.x <= p.dc2 ? 1.0f : 0.0f, d2m.y <= p.dc2 ? 1.0f : 0.0f};
+        sx = pk_fma(mm, dxm, sx);
+        sy = pk_fma(mm, dym, sy);
+        sc = pk_fma(mm, (v2f){m1.x, m1.y}, sc);
+        ss = pk_fma(mm, (v2f){m1.z, m1.w}, ss);
+        sa = pk_fma(mm, (v2f){m2.x, m2.y}, sa);
+        cnt += mm;
     }
-    // sum_j m (c_j - c_i) = sum_j m c_j - c_i cnt; targets carry the speed ratio
-    a.cntT = cntT; a.iwT = cntT; a.sxT = sxyT.x; a.syT = sxyT.y; a.trk = trk;
-    a.scT = fmaf(scsT.x, p.vratio, -ci * cntT);
-    a.ssT = fmaf(scsT.y, p.vratio, -si * cntT);
-    a.cntU = sacU.y; a.iwU = sacU.y; a.sxU = sxyU.x; a.syU = sxyU.y; a.dup = dup;
-    a.scU = fmaf(-ci, sacU.y, scsU.x);
-    a.ssU = fmaf(-si, sacU.y, scsU.y);
-    a.saU = fmaf(-ai, sacU.y, sacU.x);
+    // ---- self terms.  Post-move table: distance 0, exp2(k0).  Sequential view: odd i shares its pair
+    //      with j = i - 1 < i, so it saw its own post-move pose (d = 0); even i saw its own pre-move pose.
+    const bool odd = i & 1;
+    const float dxs = odd ? 0.0f : xo - xi, dys = odd ? 0.0f : yo - yi;
+    float d2s = dist2(dxs, dys);
+    if (Z3) { const float dzs = odd ? 0.0f : zo - zi; d2s = fmaf(dzs, dzs, d2s); }
+    const float ms = (d2s <= p.dc2) ? 1.0f : 0.0f;
+    a.dup = dup.x + dup.y - fast_exp2(p.exp_k0);
+    a.cntU = cnt.x + cnt.y - ms; a.iwU = a.cntU;
+    a.sxU = sx.x + sx.y - ms * dxs;
+    a.syU = sy.x + sy.y - ms * dys;
+    // sum_j m (c_j - c_i) = sum_j m c_j - c_i cnt
+    a.scU = fmaf(-ci, a.cntU, sc.x + sc.y - ms * (odd ? ci : co));
+    a.ssU = fmaf(-si, a.cntU, ss.x + ss.y - ms * (odd ? si : so));
+    a.saU = fmaf(-ai, a.cntU, sa.x + sa.y - ms * (odd ? ai : ao));
 }
 
 // Literal form with the uav.py:165/179 weight min(dist((rel_x, rel_y), (abs_x, abs_y)), 1).
 // It differs from 1 only when the UAV sits within ~2.5 m of the origin, so this path runs
-// for the few wavefronts that hold such a UAV and favours clarity over speed.
-template <int N_, int M_, bool Z3>
-__device__ __forceinline__ void sweep_weighted(const StepParams &p, int N, int M, int ebaseT, int i,
-                                            const float4 *__restrict__ rowNew, const float4 *__restrict__ rowOld,
-                                            const float4 *__restrict__ ttab,
-                                            const float *__restrict__ tzt, unsigned *__restrict__ covw, int covbase,
-                                            float xi, float yi, float zi, float ci, float si, float ai, Acc &a)
+// for the few wavefronts that hold such a UAV and favours clarity over speed: one agent at
+// a time, the reference's own j != i test and per-agent j < i copy choice.
+template <bool Z3>
+__device__ __forceinline__ void sweep_weighted(const StepParams &p, int N, int M, int i,
+                                               const float4 *__restrict__ rowNew, const float4 *__restrict__ rowOld,
+                                               const float4 *__restrict__ trow, const v2f *__restrict__ tzrow,
+                                               unsigned *__restrict__ covw, int covbase,
+                                               float xi, float yi, float zi, float ci, float si, float ai, Acc &a)
 {
     a = Acc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned bits = 0;
 #pragma unroll 1
     for (int k = 0; k < M; ++k) {
-        const float4 tg = ttab[ebaseT + k];
-        const float dx = tg.x - xi, dy = tg.y - yi;
-        const v2f sq = (v2f){dx, dy} * (v2f){dx, dy};        // same products as the fast path
-        float d2 = sq.x + sq.y;
-        if (Z3) {
-            const float dz = tzt[ebaseT + k] - zi;
-            d2 = fmaf(dz, dz, d2);
-        }
+        const float *f = reinterpret_cast<const float *>(trow + (k >> 1) * 2);
+        const int b = k & 1;
+        const float dx = f[b] - xi, dy = f[2 + b] - yi, tc = f[4 + b], ts = f[6 + b];
+        float d2 = dist2(dx, dy);
+        if (Z3) { const float dz = reinterpret_cast<const float *>(tzrow)[k] - zi; d2 = fmaf(dz, dz, d2); }
         const float d = fast_sqrt(d2);
         const bool in = d2 <= p.dp2;
         const float m = in ? 1.0f : 0.0f;
         const float rx = dx * p.inv_dp - xi, ry = dy * p.inv_dp - yi;
         const float iw = in ? 1.0f / fminf(sqrtf(rx * rx + ry * ry), 1.0f) : 0.0f;
-        a.scT = fmaf(iw, tg.z * p.vratio - ci, a.scT);
-        a.ssT = fmaf(iw, tg.w * p.vratio - si, a.ssT);
+        a.scT = fmaf(iw, tc * p.vratio - ci, a.scT);
+        a.ssT = fmaf(iw, ts * p.vratio - si, a.ssT);
         a.cntT += m;
         a.iwT += iw;
         a.sxT = fmaf(iw, dx, a.sxT);
@@ -249,16 +292,12 @@ __device__ __forceinline__ void sweep_weighted(const StepParams &p, int N, int M
 #pragma unroll 1
     for (int j = 0; j < N; ++j) {
         const bool other = (j != i);
-        const float4 *rs = (j < i) ? rowNew : rowOld;
-        const float4 nw = rowNew[j * 4];
-        const float4 mx = rs[j * 4];
-        const float4 ax = rs[j * 4 + 1];
-        const float am = ax.x;
+        const UavRow nw = uav_elem(rowNew, j);
+        const UavRow mx = uav_elem((j < i) ? rowNew : rowOld, j);
         const float dxn = nw.x - xi, dyn = nw.y - yi, dxm = mx.x - xi, dym = mx.y - yi;
-        const v2f sqn = (v2f){dxn, dyn} * (v2f){dxn, dyn}, sqm = (v2f){dxm, dym} * (v2f){dxm, dym};
-        float d2n = sqn.x + sqn.y, d2m = sqm.x + sqm.y;
+        float d2n = dist2(dxn, dyn), d2m = dist2(dxm, dym);
         if (Z3) {
-            const float dzn = rowNew[j * 4 + 1].z - zi, dzm = ax.z - zi;
+            const float dzn = nw.z - zi, dzm = mx.z - zi;
             d2n = fmaf(dzn, dzn, d2n);
             d2m = fmaf(dzm, dzm, d2m);
         }
@@ -268,9 +307,9 @@ __device__ __forceinline__ void sweep_weighted(const StepParams &p, int N, int M
         const float m = inm ? 1.0f : 0.0f;
         const float rx = dxm * p.inv_dc - xi, ry = dym * p.inv_dc - yi;
         const float iw = inm ? 1.0f / fminf(sqrtf(rx * rx + ry * ry), 1.0f) : 0.0f;
-        a.scU = fmaf(iw, mx.z - ci, a.scU);
-        a.ssU = fmaf(iw, mx.w - si, a.ssU);
-        a.saU = fmaf(iw, am - ai, a.saU);
+        a.scU = fmaf(iw, mx.c - ci, a.scU);
+        a.ssU = fmaf(iw, mx.s - si, a.ssU);
+        a.saU = fmaf(iw, mx.a - ai, a.saU);
         a.cntU += m;
         a.iwU += iw;
         a.sxU = fmaf(iw, dxm, a.sxU);
@@ -285,23 +324,21 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     const int N = N_ > 0 ? N_ : p.N;
     const int M = M_ > 0 ? M_ : p.M;
     const int E = p.E;
-    const int EN = E * N, EM = E * M;
+    const int EN = E * N;
     const int CW = (M + 31) >> 5;
+    const int MP = pairs_of(M);
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;
 
     // ---- LDS carve (float4 first: the dynamic base is 16-B aligned)
-    // UAV table: per (env, uav) two 32-B rows (copy 0 / copy 1, one of them "post-move of this
-    // step"), each (x, y, cos h, sin h | action, 1, z, -).  The env stride carries 32 B of padding so
-    // that rows of different envs read by one lane group start in different banks.
-    const int ustride = N * 4 + 2;        // float4 units per env
-    float4 *utab = smem4;                 // [E][N][2][2]
-    float4 *ttab = utab + E * ustride;    // [EM]     (x, y, cos h, sin h)
-    float *fb = reinterpret_cast<float *>(ttab + EM);
-    float *thd = fb;   fb += EM;          // [EM]     target heading
-    float *rawl = fb;  fb += EN;          // [EN]     raw reward (cooperative modes)
-    float *tzt = fb;   if (Z3) fb += EM;
-    unsigned *covw = reinterpret_cast<unsigned *>(fb);   // [2][E * CW]
+    const int ustride = ustride_of(N), tstride = tstride_of(M);
+    float4 *utab = smem4;                        // [E][pairs][2 copies][3]
+    float4 *ttab = utab + E * ustride;           // [E][pairs][2]
+    float *fb = reinterpret_cast<float *>(ttab + E * tstride);
+    float *thd = fb;   fb += E * M;              // [E][M]      target heading
+    float *rawl = fb;  fb += E * (N + 1);        // [E][N + 1]  raw reward (cooperative modes), pair-padded
+    float *tzf = fb;   if (Z3) fb += E * MP * 2; // [E][pairs] (z0, z1)
+    unsigned *covw = reinterpret_cast<unsigned *>(fb);   // [2][E * CW] (+ 2 words, MAAC-R pair emission)
 
     const int grp = xcd_group(blockIdx.x, gridDim.x);
     const int env0 = grp * E;
@@ -312,7 +349,8 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     const bool active = (tid < EN) && (e < envs_here);
     const size_t g = (size_t)b * N + i;          // flat (env, uav)
     const size_t BN = (size_t)p.B * N;
-    const int ebaseU = e * N, ebaseT = e * M;
+    float4 *const uenv = utab + e * ustride;     // this lane's environment
+    float4 *const tenv = ttab + e * tstride;
 
     float x = 0, y = 0, z = 0, h = 0, c = 1, s = 0;
     int a_prev = 0, count = 0;
@@ -327,23 +365,45 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         if (Z3) z = S.uz[g];
         sincos_any(h, &s, &c);
         count = S.step_count[b];
-        float4 *own = utab + e * ustride + i * 4 + 2;           // "previous" copy for step 0
-        own[0] = make_float4(x, y, c, s);
-        own[1] = make_float4((float)a_prev, 1.0f, z, 0.0f);
+        uav_store(uenv + 3, i, x, y, c, s, (float)a_prev, z);            // "previous" copy (1) for step 0
+        if ((N & 1) && i == N - 1) {                                      // padding agent of the last pair
+            uav_store(uenv, N, kFar, kFar, 0.f, 0.f, 0.f, 0.f);
+            uav_store(uenv + 3, N, kFar, kFar, 0.f, 0.f, 0.f, 0.f);
+        }
+        if (i == 0) {
+            rawl[e * (N + 1) + N] = 0.0f;
+            for (int w = 0; w < CW; ++w) covw[e * CW + w] = covw[E * CW + e * CW + w] = 0;
+            if (M & 1) {                                                  // padding target
+                float *f = reinterpret_cast<float *>(tenv + (M >> 1) * 2);
+                f[1] = kFar; f[3] = kFar; f[5] = 0.f; f[7] = 0.f;
+                if (Z3) tzf[e * MP * 2 + M] = 0.f;
+            }
+        }
     }
     for (int q = tid; q < envs_here * M; q += nthreads) {
+        const int te = q / M, k = q - te * M;
         const size_t gt = (size_t)env0 * M + q;
         const float th = S.th[gt];
         float ts, tc;
         sincos_any(th, &ts, &tc);
-        ttab[q] = make_float4(S.tx[gt], S.ty[gt], tc, ts);
+        float *f = reinterpret_cast<float *>(ttab + te * tstride + (k >> 1) * 2);
+        const int bb = k & 1;
+        f[bb] = S.tx[gt]; f[2 + bb] = S.ty[gt]; f[4 + bb] = tc; f[6 + bb] = ts;
         thd[q] = th;
-        if (Z3) tzt[q] = S.tz[gt];
+        if (Z3) tzf[te * MP * 2 + k] = S.tz[gt];
     }
-    if (active && i == 0)
-        for (int w = 0; w < CW; ++w) covw[e * CW + w] = covw[E * CW + e * CW + w] = 0;
     int act = 0;
     if (active) act = p.actions[g];
+    // Per-lane constants of the step loop: this lane's own slots in both table copies, and (when the
+    // workgroup has at least one lane per target, as in every benchmark shape) its target's slot.
+    float *const own0 = reinterpret_cast<float *>(uenv + (i >> 1) * 6) + (i & 1);
+    const bool one_target_per_lane = E * M <= nthreads;
+    const bool my_target = tid < envs_here * M;
+    float *tgt = reinterpret_cast<float *>(ttab);
+    if (my_target) {
+        const int te = tid / M, k = tid - te * M;
+        tgt = reinterpret_cast<float *>(ttab + te * tstride + (k >> 1) * 2) + (k & 1);
+    }
     __syncthreads();
 
     for (int t = 0; t < p.T; ++t) {
@@ -351,30 +411,41 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         const int cbuf = (t & 1) * E * CW;
 
         // ---- P1a: targets (target.py:27-60); straight flight, mirror at the walls
-        for (int q = tid; q < envs_here * M; q += nthreads) {
-            float4 tg = ttab[q];
-            float th = thd[q];
-            tg.x = fmaf(p.dtv_t, tg.z, tg.x);
-            tg.y = fmaf(p.dtv_t, tg.w, tg.y);
+        auto advance_target = [&](float *f, int q) {      // f -> x slot of the target; y, cos, sin at +2, +4, +6
+            float tx = f[0], ty = f[2];
+            tx = fmaf(p.dtv_t, f[4], tx);
+            ty = fmaf(p.dtv_t, f[6], ty);
+            f[0] = tx; f[2] = ty;
             bool turned = false;
-            if (0.0f > tg.y || tg.y > p.y_max) {
-                th = -th;
+            float th = 0.0f;
+            if (0.0f > ty || ty > p.y_max) {
+                th = -thd[q];
                 turned = true;
-            } else if (tg.x < 0.0f || tg.x > p.x_max) {
+            } else if (tx < 0.0f || tx > p.x_max) {
+                th = thd[q];
                 th = (th > 0.0f) ? kPi - th : -kPi - th;
                 turned = true;
             }
             if (turned) {   // rare: recompute so that T fused steps == T single steps bit for bit
-                sincos_any(th, &tg.w, &tg.z);
+                float ns, nc;
+                sincos_any(th, &ns, &nc);
+                f[4] = nc; f[6] = ns;
                 thd[q] = th;
             }
-            ttab[q] = tg;
+        };
+        if (one_target_per_lane) {
+            if (my_target) advance_target(tgt, tid);
+        } else {
+            for (int q = tid; q < envs_here * M; q += nthreads) {
+                const int te = q / M, k = q - te * M;
+                advance_target(reinterpret_cast<float *>(ttab + te * tstride + (k >> 1) * 2) + (k & 1), q);
+            }
         }
 
         // ---- P1b: own kinematics (uav.py:83-99); position uses the OLD heading
         int a_now = 0;
         float ai = 0;
-        float xo = x, yo = y, zo = z, co = c, so = s, ao = (float)a_prev;   // pre-move pose: the j == i self term
+        const float xo = x, yo = y, zo = z, co = c, so = s, ao = (float)a_prev;   // pre-move pose: even-i self term
         if (active) {
             a_now = min(max(act, 0), p.na_total - 1);
             int a_turn = a_now, a_climb = 0;
@@ -389,29 +460,31 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             h = wrap_heading(fmaf((float)(2 * a_turn + 1 - p.na), p.turn_unit, h));
             sincos_wrapped(h, &s, &c);
             ai = (float)a_now;
-            float4 *own = utab + e * ustride + i * 4 + pn * 2;
-            own[0] = make_float4(x, y, c, s);
-            own[1] = make_float4(ai, 1.0f, z, 0.0f);
+            {
+                float *f = own0 + pn * 12;                   // copy pn of this lane's pair row
+                f[0] = x; f[2] = y; f[4] = c; f[6] = s; f[8] = ai; f[10] = z;
+            }
             if (t + 1 < p.T) act = p.actions[tg_off + BN];   // prefetch next step's action
+            if (i == 0)
+                for (int w = 0; w < CW; ++w) covw[cbuf + e * CW + w] = 0;
         }
-        if (active && i == 0)
-            for (int w = 0; w < CW; ++w) covw[cbuf + e * CW + w] = 0;
         __syncthreads();
 
         // ---- P2: pair sweeps
         float o[12], tt = 0, bp = 0, dupn = 0, raw = 0;
+        const float4 *rowNew = uenv + pn * 3;
+        const float4 *rowOld = uenv + (pn ^ 1) * 3;
+        const v2f *tzrow = reinterpret_cast<const v2f *>(tzf + e * MP * 2);
         if (active) {
             Acc acc;
             // weight of uav.py:165 can be < 1 only near the origin; wave-uniform branch
             const bool near0 = fabsf(x) < 2.5f && fabsf(y) < 2.5f;
-            const float4 *rowNew = utab + e * ustride + pn * 2;
-            const float4 *rowOld = utab + e * ustride + (pn ^ 1) * 2;
             if (__builtin_expect(__any(near0), 0))
-                sweep_weighted<N_, M_, Z3>(p, N, M, ebaseT, i, rowNew, rowOld, ttab, tzt, covw,
-                                           cbuf + e * CW, x, y, z, c, s, ai, acc);
+                sweep_weighted<Z3>(p, N, M, i, rowNew, rowOld, tenv, tzrow, covw, cbuf + e * CW,
+                                   x, y, z, c, s, ai, acc);
             else
-                sweep_fast<N_, M_, Z3>(p, N, M, ebaseT, i, rowNew, rowOld, ttab, tzt, covw,
-                                       cbuf + e * CW, x, y, z, c, s, ai, xo, yo, zo, co, so, ao, acc);
+                sweep_fast<N_, M_, Z3>(p, N, M, i, rowNew, rowOld, tenv, tzrow, covw, cbuf + e * CW,
+                                       x, y, z, c, s, ai, xo, yo, zo, co, so, ao, acc);
 
             // ---- P3: local state (uav.py:156-190)
             if (acc.cntU > 0.0f) {
@@ -445,7 +518,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             bp = (fminf(fmaxf(bpun, -0.5f), 0.0f) + 0.5f) * 2.0f - 1.0f;
             dupn = (fminf(fmaxf(acc.dup * -0.5f, p.dup_floor), 0.0f) - p.dup_floor) * p.inv_dup - 1.0f;
             raw = p.alpha * tt + p.beta * bp + p.gamma * dupn;
-            if (MODE != UAVTRACK_REWARD_RAW) rawl[tid] = raw;
+            if (MODE != UAVTRACK_REWARD_RAW) rawl[e * (N + 1) + i] = raw;
         }
         __syncthreads();
 
@@ -453,21 +526,27 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         if (active) {
             float r = raw;
             if (MODE == UAVTRACK_REWARD_MEAN) {
-                if (p.coop != 0.0f) {   // uav.py:293-310
-                    float sum = 0, cnt = 0;
-                    const float4 *rowNew = utab + e * ustride + pn * 2;
+                if (p.coop != 0.0f) {   // uav.py:293-310; neighbours on post-move poses, self subtracted after
+                    v2f sum = splat(0.f), cnt = splat(0.f);
+                    const v2f xi2 = splat(x), yi2 = splat(y), zi2 = splat(z);
+                    const int NP = pairs_of(N_ > 0 ? N_ : N);
 #pragma unroll UAVTRACK_UNROLL_U
-                    for (int j = 0; j < (N_ > 0 ? N_ : N); ++j) {
-                        const float4 nw = rowNew[j * 4];
-                        const v2f dd = (v2f){nw.x, nw.y} - (v2f){x, y};
-                        const v2f sq = dd * dd;                  // same products as the sweeps
-                        float d2 = sq.x + sq.y;
-                        if (Z3) { const float dz = rowNew[j * 4 + 1].z - z; d2 = fmaf(dz, dz, d2); }
-                        const bool nb = (j != i) && d2 <= p.dp2;
-                        sum += nb ? rawl[ebaseU + j] : 0.0f;
-                        cnt += nb ? 1.0f : 0.0f;
+                    for (int jp = 0; jp < NP; ++jp) {
+                        const float4 n0 = rowNew[jp * 6];
+                        const v2f dx = (v2f){n0.x, n0.y} - xi2, dy = (v2f){n0.z, n0.w} - yi2;
+                        v2f d2 = pk_fma(dy, dy, dx * dx);
+                        if (Z3) {
+                            const float4 n2 = rowNew[jp * 6 + 2];
+                            const v2f dz = (v2f){n2.z, n2.w} - zi2;
+                            d2 = pk_fma(dz, dz, d2);
+                        }
+                        const v2f mm = {d2.x <= p.dp2 ? 1.0f : 0.0f, d2.y <= p.dp2 ? 1.0f : 0.0f};
+                        const float *rw = rawl + e * (N + 1) + 2 * jp;    // (N + 1 may be odd: no 8-B alignment)
+                        sum = pk_fma(mm, (v2f){rw[0], rw[1]}, sum);
+                        cnt += mm;
                     }
-                    r = (cnt > 0.0f) ? (1.0f - p.coop) * raw + p.coop * sum / cnt : 0.0f;
+                    const float nsum = sum.x + sum.y - raw, ncnt = cnt.x + cnt.y - 1.0f;   // minus self (d = 0)
+                    r = (ncnt > 0.0f) ? (1.0f - p.coop) * raw + p.coop * nsum / ncnt : 0.0f;
                 }
             }
             r = fminf(fmaxf(r, -1.0f), 1.0f);   // clip_and_normalize(reward, -1, 1), environment.py:225
@@ -508,14 +587,11 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             if (tid == 0) wg_cnt[0] = 0;
             __syncthreads();
             int mine = 0, slot = 0;
-            const float4 *rowNew = utab + e * ustride + pn * 2;
             if (active) {
                 for (int j = i + 1; j < N; ++j) {
-                    const float4 nw = rowNew[j * 4];
-                    const v2f dd = (v2f){nw.x, nw.y} - (v2f){x, y};
-                    const v2f sq = dd * dd;
-                    float d2 = sq.x + sq.y;
-                    if (Z3) { const float dz = rowNew[j * 4 + 1].z - z; d2 = fmaf(dz, dz, d2); }
+                    const UavRow nw = uav_elem(rowNew, j);
+                    float d2 = dist2(nw.x - x, nw.y - y);
+                    if (Z3) { const float dz = nw.z - z; d2 = fmaf(dz, dz, d2); }
                     mine += (d2 <= p.dp2) ? 1 : 0;
                 }
                 if (mine) slot = (int)atomicAdd(&wg_cnt[0], (unsigned)mine);
@@ -526,11 +602,9 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             if (active && mine) {
                 uint2 *dst = p.pairs + wg_cnt[1] + slot;
                 for (int j = i + 1; j < N; ++j) {
-                    const float4 nw = rowNew[j * 4];
-                    const v2f dd = (v2f){nw.x, nw.y} - (v2f){x, y};
-                    const v2f sq = dd * dd;
-                    float d2 = sq.x + sq.y;
-                    if (Z3) { const float dz = rowNew[j * 4 + 1].z - z; d2 = fmaf(dz, dz, d2); }
+                    const UavRow nw = uav_elem(rowNew, j);
+                    float d2 = dist2(nw.x - x, nw.y - y);
+                    if (Z3) { const float dz = nw.z - z; d2 = fmaf(dz, dz, d2); }
                     if (d2 <= p.dp2) *dst++ = make_uint2((unsigned)g, (unsigned)j);
                 }
             }
@@ -545,19 +619,20 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         if (i == 0) S.step_count[b] = count;
     }
     for (int q = tid; q < envs_here * M; q += nthreads) {
+        const int te = q / M, k = q - te * M;
         const size_t gt = (size_t)env0 * M + q;
-        const float4 tg = ttab[q];
-        S.tx[gt] = tg.x; S.ty[gt] = tg.y; S.th[gt] = thd[q];
+        const float *f = reinterpret_cast<const float *>(ttab + te * tstride + (k >> 1) * 2);
+        S.tx[gt] = f[k & 1]; S.ty[gt] = f[2 + (k & 1)]; S.th[gt] = thd[q];
     }
     if (p.ep_sums) {
-        __syncthreads();                       // everyone is done with utab
-        float4 *eps = utab;
+        __syncthreads();                       // everyone is done with the tables
+        float4 *eps = utab;                    // E * ustride >= E * N float4 (see lds_bytes_for)
         if (active) eps[tid] = make_float4(er, ett, ebp, edup);
         __syncthreads();
         if (active && i == 0) {
             float4 sum = make_float4(0, 0, 0, 0);
             for (int j = 0; j < N; ++j) {       // fixed order: bitwise reproducible
-                const float4 v = eps[ebaseU + j];
+                const float4 v = eps[e * N + j];
                 sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
             }
             const float inv_n = 1.0f / (float)N;
@@ -570,10 +645,10 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
 
 size_t lds_bytes_for(int E, int N, int M, bool z3)
 {
-    const size_t EN = (size_t)E * N, EM = (size_t)E * M, CW = (M + 31) / 32;
-    size_t f4 = (size_t)E * (N * 4 + 2) + EM;
-    size_t f = EM + EN + (z3 ? EM : 0) + 2 * E * CW + 2;
-    return f4 * 16 + f * 4;
+    const size_t CW = (M + 31) / 32, MP = pairs_of(M);
+    const size_t f4 = (size_t)E * ustride_of(N) + (size_t)E * tstride_of(M);
+    const size_t f = (size_t)E * M + (size_t)E * (N + 1) + (z3 ? (size_t)E * MP * 2 : 0) + 2 * E * CW + 2;
+    return (f4 * 16 + f * 4 + 15) & ~(size_t)15;   // ustride >= 3 N float4 per env, so ep_sums staging (E N float4) fits
 }
 
 using KernelFn = void (*)(const StepParams);
