@@ -464,7 +464,9 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                 float *f = own0 + pn * 12;                   // copy pn of this lane's pair row
                 f[0] = x; f[2] = y; f[4] = c; f[6] = s; f[8] = ai; f[10] = z;
             }
+#ifndef UAVTRACK_EXPERIMENT_NO_ACTION_LOADS
             if (t + 1 < p.T) act = p.actions[tg_off + BN];   // prefetch next step's action
+#endif
             if (i == 0)
                 for (int w = 0; w < CW; ++w) covw[cbuf + e * CW + w] = 0;
         }
