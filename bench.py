@@ -331,6 +331,27 @@ def main():
                 "roofline_achieved_GBs": ach, "roofline_frac": ach / HBM_PEAK_GBS,
                 "avg_launch_ms": rs["kernel_ms_total"] / rs["launches"], "geometry": rs["geometry"],
             }
+        if world == 1 and not args.no_extras and args.reward != "pmi":
+            # closed loop: actor forward [B*N,12] -> sample -> uavtrack_step per step, eager
+            # launches vs the same steps replayed from a HIP graph
+            torch.manual_seed(args.seed)
+            actor = uavtrack.ActorMLP(action_dim=12 * (3 if args.dim == 3 else 1)).to(device)
+            cl = {}
+            for mode in ("eager", "graph"):
+                env = make_env(uavtrack, args, B, device)
+                ro = uavtrack.BatchedRollout(env, actor, steps_per_graph=10, use_graph=(mode == "graph"))
+                ro.reset(seed=args.seed)
+                ro.run(40)
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                ro.run(400)
+                torch.cuda.synchronize(device)
+                dt = time.perf_counter() - t0
+                cl[mode] = {"agent_steps_per_s": B * N * 400 / dt, "ms_per_step": dt * 1e3 / 400}
+                env.close()
+            cl["note"] = ("reference-shaped shared actor (12-256-12 softmax, random init) + categorical sample + "
+                          "uavtrack_step + episode accumulators, all on device; graph = 10 steps per HIP-graph replay")
+            line["closed_loop"] = cl
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
             line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

@@ -146,6 +146,13 @@ int uavtrack_step_many(uavtrack_env *env, int32_t T, const int32_t *actions,
                        float *obs, float *reward, float *terms,
                        int32_t *covered, uint8_t *done, float *ep_sums, void *stream);
 
+/* uavtrack_step that also ADDS this step's contribution to the caller's running episode
+ * accumulators ep_sums [B][5] (same five sums as uavtrack_step_many, train.py:181-192), so a
+ * closed-loop driver needs no reduction kernels of its own.  ep_sums must not be NULL. */
+int uavtrack_step_accumulate(uavtrack_env *env, const int32_t *actions,
+                             float *obs, float *reward, float *terms,
+                             int32_t *covered, uint8_t *done, float *ep_sums, void *stream);
+
 /* MAAC-R accounting for reports: out[0] = neighbour pairs scored by the PMI network since
  * the weights were set (each unordered pair once per step).  Synchronises `stream`. */
 int uavtrack_pmi_pairs_scored(uavtrack_env *env, uint64_t *out, void *stream);

@@ -308,7 +308,8 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
 }
 
 static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float *obs, float *reward, float *terms,
-                     int32_t *covered, uint8_t *done, float *ep_sums, void *stream, const char *who)
+                     int32_t *covered, uint8_t *done, float *ep_sums, void *stream, const char *who,
+                     bool accumulate = false)
 {
     if (!env) return fail("%s: null handle", who);
     if (T < 1) return fail("%s: T must be >= 1 (got %d)", who, T);
@@ -321,6 +322,7 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
     p.obs = obs; p.reward = reward; p.terms = terms; p.raw_out = nullptr;
     p.covered = covered; p.done = done; p.ep_sums = ep_sums;
     p.pairs = nullptr; p.pair_count = nullptr;
+    p.ep_accumulate = accumulate ? 1 : 0;
     if (env->cfg.reward_mode != UAVTRACK_REWARD_PMI) {
         p.T = T;
         HIP_TRY(launch_rollout(env, p, st));
@@ -331,7 +333,7 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
     if (!env->pmi.blob) return fail("%s: reward_mode PMI needs uavtrack_set_pmi_weights first", who);
     const uavtrack_config &c = env->cfg;
     const size_t BN = (size_t)c.n_envs * c.n_uav;
-    if (ep_sums) HIP_TRY(hipMemsetAsync(ep_sums, 0, (size_t)c.n_envs * 5 * sizeof(float), st));
+    if (ep_sums && !accumulate) HIP_TRY(hipMemsetAsync(ep_sums, 0, (size_t)c.n_envs * 5 * sizeof(float), st));
     p.T = 1;
     p.ep_sums = nullptr;
     p.raw_out = env->raw;
@@ -357,6 +359,14 @@ int uavtrack_step(uavtrack_env *env, const int32_t *actions, float *obs, float *
                   int32_t *covered, uint8_t *done, void *stream)
 {
     return run_steps(env, 1, actions, obs, reward, terms, covered, done, nullptr, stream, "uavtrack_step");
+}
+
+int uavtrack_step_accumulate(uavtrack_env *env, const int32_t *actions, float *obs, float *reward, float *terms,
+                             int32_t *covered, uint8_t *done, float *ep_sums, void *stream)
+{
+    if (!ep_sums) return fail("uavtrack_step_accumulate: ep_sums is null");
+    return run_steps(env, 1, actions, obs, reward, terms, covered, done, ep_sums, stream,
+                     "uavtrack_step_accumulate", true);
 }
 
 int uavtrack_step_many(uavtrack_env *env, int32_t T, const int32_t *actions, float *obs, float *reward,

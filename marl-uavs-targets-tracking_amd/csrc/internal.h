@@ -38,6 +38,7 @@ struct StepParams {
     unsigned *pair_count;
     // geometry
     int32_t B, N, M, E, T, na, na_total, horizon;
+    int32_t ep_accumulate;   // 1: ep_sums += (uavtrack_step_accumulate), 0: ep_sums = sums of this launch
     // constants
     float x_max, y_max, z_max;
     float dtv_u, dtv_t;          // dt * v_max of UAVs / targets

@@ -639,8 +639,13 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             }
             const float inv_n = 1.0f / (float)N;
             float *ep = p.ep_sums + (size_t)b * 5;
-            ep[0] = sum.x * inv_n; ep[1] = sum.y * inv_n; ep[2] = sum.z * inv_n; ep[3] = sum.w * inv_n;
-            ep[4] = (float)ecov;
+            if (p.ep_accumulate) {
+                ep[0] += sum.x * inv_n; ep[1] += sum.y * inv_n; ep[2] += sum.z * inv_n; ep[3] += sum.w * inv_n;
+                ep[4] += (float)ecov;
+            } else {
+                ep[0] = sum.x * inv_n; ep[1] = sum.y * inv_n; ep[2] = sum.z * inv_n; ep[3] = sum.w * inv_n;
+                ep[4] = (float)ecov;
+            }
         }
     }
 }

@@ -10,7 +10,8 @@ from .env import BatchedUavEnv  # noqa: F401
 from .compat import Environment  # noqa: F401
 from .pmi import fold_pmi_state_dict  # noqa: F401
 from .sharding import shard_range, gather_rollout_summary  # noqa: F401
+from .rollout import ActorMLP, BatchedRollout, sample_actions  # noqa: F401
 from . import _lib  # noqa: F401
 
 __all__ = ["EnvConfig", "RewardMode", "BatchedUavEnv", "Environment", "fold_pmi_state_dict",
-           "shard_range", "gather_rollout_summary"]
+           "shard_range", "gather_rollout_summary", "ActorMLP", "BatchedRollout", "sample_actions"]

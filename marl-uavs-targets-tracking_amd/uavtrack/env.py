@@ -93,15 +93,24 @@ class BatchedUavEnv:
                                             _ptr(obs), self._stream()), "uavtrack_reset")
         return obs
 
-    def step(self, actions, want_terms: bool = True):
+    def step(self, actions, want_terms: bool = True, ep_sums: Optional[torch.Tensor] = None):
+        """`ep_sums` [B, 5] (float32, this device): running episode accumulators the kernel adds
+        this step's contribution to (train.py:181-192)."""
         a = self._actions(actions, (self.B, self.N))
         obs = self._empty((self.B, self.N, _lib.OBS_DIM), torch.float32)
         reward = self._empty((self.B, self.N), torch.float32)
         terms = self._empty((3, self.B, self.N), torch.float32) if want_terms else None
         covered = self._empty((self.B,), torch.int32)
         done = self._empty((self.B,), torch.uint8)
-        _lib.check(self._lib.uavtrack_step(self._h, _ptr(a), _ptr(obs), _ptr(reward), _ptr(terms),
-                                           _ptr(covered), _ptr(done), self._stream()), "uavtrack_step")
+        if ep_sums is not None:
+            if ep_sums.shape != (self.B, 5) or ep_sums.dtype != torch.float32 or not ep_sums.is_contiguous():
+                raise ValueError("ep_sums must be a contiguous float32 [B, 5] tensor")
+            _lib.check(self._lib.uavtrack_step_accumulate(self._h, _ptr(a), _ptr(obs), _ptr(reward), _ptr(terms),
+                                                          _ptr(covered), _ptr(done), _ptr(ep_sums), self._stream()),
+                       "uavtrack_step_accumulate")
+        else:
+            _lib.check(self._lib.uavtrack_step(self._h, _ptr(a), _ptr(obs), _ptr(reward), _ptr(terms),
+                                               _ptr(covered), _ptr(done), self._stream()), "uavtrack_step")
         self.info = {"terms": terms, "covered": covered}
         return obs, reward, done.bool()
 

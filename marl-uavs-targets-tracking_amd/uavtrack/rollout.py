@@ -1,0 +1,99 @@
+"""Closed-loop batched rollout driver: the caller side of the hot path.
+
+The reference's `train.operate_epoch` (src/train.py:142-196) runs, per step, N batch-1 actor
+forwards with a host round trip each (`actor_critic.py:138-148`), then `env.step`.  Here one
+`[B*N, 12]` actor forward, a categorical sample and `uavtrack_step` are chained on one stream
+with nothing returning to the host, and `steps_per_graph` such steps are captured once into a
+HIP graph (`torch.cuda.CUDAGraph`; the library's launches are stream-ordered and allocation-free,
+so they capture like any other kernel) and replayed -- a per-step launch sequence is otherwise
+host-bound at this batch size.  Episode accumulators follow train.py:181-192.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import torch
+
+from .env import BatchedUavEnv
+
+
+class ActorMLP(torch.nn.Module):
+    """Same shape as the reference's shared actor `FnnPolicyNet` (src/models/actor_critic.py:85-98):
+    Linear(12, hidden) - ReLU - Linear(hidden, na) - softmax.  Weights load from its state_dict."""
+
+    def __init__(self, state_dim: int = 12, hidden_dim: int = 256, action_dim: int = 12):
+        super().__init__()
+        self.fc1 = torch.nn.Linear(state_dim, hidden_dim)
+        self.fc2 = torch.nn.Linear(hidden_dim, action_dim)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return torch.softmax(self.fc2(torch.relu(self.fc1(x))), dim=-1)
+
+
+def sample_actions(probs: torch.Tensor) -> torch.Tensor:
+    """Categorical(probs).sample() for [B, N, na] -> int32 [B, N] (actor_critic.py:145-147), drawn with
+    the exponential-race form argmax_i p_i / E_i, E_i ~ Exp(1): three elementwise kernels instead of
+    torch.multinomial's per-row search."""
+    return (probs / torch.empty_like(probs).exponential_()).argmax(dim=-1).to(torch.int32)
+
+
+class BatchedRollout:
+    def __init__(self, env: BatchedUavEnv, policy: Callable[[torch.Tensor], torch.Tensor],
+                 select: Callable[[torch.Tensor], torch.Tensor] = sample_actions,
+                 steps_per_graph: int = 8, use_graph: bool = True):
+        self.env, self.policy, self.select = env, policy, select
+        self.k = max(1, int(steps_per_graph))
+        self.use_graph = use_graph
+        B = env.B
+        dev = env.device
+        self.obs = torch.empty(B, env.N, 12, device=dev)               # static buffers (graph I/O)
+        self.ep = torch.zeros(B, 5, device=dev)                        # sum_t mean_i reward, 3 terms, covered
+        self.last_reward = torch.empty(B, env.N, device=dev)
+        self._graph: Optional[torch.cuda.CUDAGraph] = None
+
+    # one closed-loop step on the current stream; everything stays on the device
+    def _one_step(self):
+        with torch.no_grad():
+            actions = self.select(self.policy(self.obs))
+        obs, reward, _ = self.env.step(actions, ep_sums=self.ep)   # the kernel adds to the accumulators
+        self.obs.copy_(obs)
+        self.last_reward.copy_(reward)
+
+    def _capture(self):
+        # warm up on a side stream (allocator pools, lazy inits), then capture k steps
+        s = torch.cuda.Stream(device=self.env.device)
+        s.wait_stream(torch.cuda.current_stream(self.env.device))
+        with torch.cuda.stream(s):
+            state = self.env.get_state()
+            obs0, ep0 = self.obs.clone(), self.ep.clone()
+            for _ in range(2):
+                self._one_step()
+            self.env.set_state(**state)                    # undo the warm-up steps
+            self.obs.copy_(obs0); self.ep.copy_(ep0)
+        torch.cuda.current_stream(self.env.device).wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        state = self.env.get_state()
+        obs0, ep0 = self.obs.clone(), self.ep.clone()
+        with torch.cuda.graph(g):
+            for _ in range(self.k):
+                self._one_step()
+        self.env.set_state(**state)                        # capture does not execute; be explicit anyway
+        self.obs.copy_(obs0); self.ep.copy_(ep0)
+        self._graph = g
+
+    def reset(self, seed: int = 0):
+        self.obs.copy_(self.env.reset(seed=seed))
+        self.ep.zero_()
+
+    def run(self, steps: int) -> Dict[str, torch.Tensor]:
+        """Advance `steps` closed-loop steps; returns the episode accumulators so far."""
+        done = 0
+        if self.use_graph and steps >= self.k:
+            if self._graph is None:
+                self._capture()
+            while steps - done >= self.k:
+                self._graph.replay()
+                done += self.k
+        for _ in range(steps - done):
+            self._one_step()
+        return {"ep_sums": self.ep, "obs": self.obs, "reward": self.last_reward}
