@@ -337,8 +337,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     const int ustride = ustride_of(N), tstride = tstride_of(M);
     float4 *utab = smem4;                        // [E][pairs][2 copies][3]
     float4 *ttab = utab + E * ustride;           // [E][pairs][2]
-    float4 *ostage = ttab + E * tstride;         // [waves][64 * 3]  observation rows, staged per wavefront
-    float *fb = reinterpret_cast<float *>(ostage + (nthreads >> 6) * 192);
+    float *fb = reinterpret_cast<float *>(ttab + E * tstride);
     float *thd = fb;   fb += E * M;              // [E][M]      target heading
     float *rawl = fb;  fb += E * (N + 1);        // [E][N + 1]  raw reward (cooperative modes), pair-padded
     float *tzf = fb;   if (Z3) fb += E * MP * 2; // [E][pairs] (z0, z1)
@@ -568,6 +567,12 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             }
             er += r; ett += tt; ebp += bp; edup += dupn;
 
+            if (p.obs) {
+                float4 *op = reinterpret_cast<float4 *>(p.obs + tg_off * UAVTRACK_OBS_DIM);
+                op[0] = make_float4(o[0], o[1], o[2], o[3]);
+                op[1] = make_float4(o[4], o[5], o[6], o[7]);
+                op[2] = make_float4(o[8], o[9], o[10], o[11]);
+            }
             if (p.reward) p.reward[tg_off] = r;
             if (p.raw_out) p.raw_out[tg_off] = raw;
             if (p.terms) {
@@ -577,27 +582,6 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                 tp[2 * BN] = dupn;
             }
             a_prev = a_now;
-        }
-        // Observation rows leave through LDS: a lane's 48-B row is three float4 at a 48-B lane stride,
-        // i.e. 64 scattered 16-B pieces per store instruction.  The rows of one wavefront are contiguous
-        // in HBM (flat agent index = env0 * N + tid), so each wavefront writes them to its staging block
-        // and reads them back as consecutive float4: every store instruction then covers 1 KiB of whole
-        // 128-B lines.  Same-wavefront LDS traffic is ordered; no barrier.
-        if (p.obs) {
-            const int wv = tid >> 6, lane = tid & 63;
-            float4 *stg = ostage + wv * 192;
-            if (active) {
-                stg[lane * 3 + 0] = make_float4(o[0], o[1], o[2], o[3]);
-                stg[lane * 3 + 1] = make_float4(o[4], o[5], o[6], o[7]);
-                stg[lane * 3 + 2] = make_float4(o[8], o[9], o[10], o[11]);
-            }
-            const int valid = 3 * min(max(envs_here * N - wv * 64, 0), 64);   // active lanes are a prefix of the group
-            float4 *dst = reinterpret_cast<float4 *>(p.obs + ((size_t)t * BN + (size_t)env0 * N + wv * 64) * UAVTRACK_OBS_DIM);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int f = k * 64 + lane;
-                if (f < valid) dst[f] = stg[f];
-            }
         }
 
         // ---- MAAC-R only: emit the neighbour pairs (i < j, d <= dp on post-move poses, uav.py:278) this
@@ -672,9 +656,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
 size_t lds_bytes_for(int E, int N, int M, bool z3)
 {
     const size_t CW = (M + 31) / 32, MP = pairs_of(M);
-    const size_t wgs = ((size_t)E * N + 63) / 64 * 64;                   // see plan_geometry: E = wgs / N
-    const size_t f4 = (size_t)E * ustride_of(N) + (size_t)E * tstride_of(M) + kMaxWorkgroup / 64 * 192;
-    (void)wgs;
+    const size_t f4 = (size_t)E * ustride_of(N) + (size_t)E * tstride_of(M);
     const size_t f = (size_t)E * M + (size_t)E * (N + 1) + (z3 ? (size_t)E * MP * 2 : 0) + 2 * E * CW + 2;
     return (f4 * 16 + f * 4 + 15) & ~(size_t)15;   // ustride >= 3 N float4 per env, so ep_sums staging (E N float4) fits
 }
