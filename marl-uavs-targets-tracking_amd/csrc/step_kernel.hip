@@ -706,16 +706,22 @@ Geometry plan_geometry(const uavtrack_config &cfg)
     // chip-filling batch.  Among the candidates take the best lane utilisation; ties go to
     // the size that measured fastest (256, then 128, 512, 64).
     static const int kCandidates[] = {256, 128, 512, 64};
-    for (int wgs : kCandidates) {
-        if (forced && wgs != forced) continue;
+    auto feasible = [&](int wgs) {
         const int E = wgs / N;
-        if (E < 1) continue;
-        if (lds_bytes_for(E, N, cfg.m_targets, cfg.dim == 3) > 64 * 1024) continue;   // e.g. N = 1 with many targets
-        const int Euse = E < cfg.n_envs ? E : cfg.n_envs;
-        const double util = (double)Euse * N / wgs;
-        if (util > best_util + 0.05) { best_util = util; best = wgs; }
+        return E >= 1 && lds_bytes_for(E, N, cfg.m_targets, cfg.dim == 3) <= 64 * 1024;   // e.g. N = 1, many targets
+    };
+    // UAVTRACK_WGS (experiments) is honoured when that geometry is feasible, else ignored
+    if (forced >= 64 && forced <= kMaxWorkgroup && forced % 64 == 0 && feasible(forced)) {
+        best = forced;
+    } else {
+        for (int wgs : kCandidates) {
+            if (!feasible(wgs)) continue;
+            const int E = wgs / N;
+            const int Euse = E < cfg.n_envs ? E : cfg.n_envs;
+            const double util = (double)Euse * N / wgs;
+            if (util > best_util + 0.05) { best_util = util; best = wgs; }
+        }
     }
-    if (!best && forced >= 64 && forced <= kMaxWorkgroup && forced % 64 == 0 && forced / N >= 1) best = forced;
     if (!best) return g;
     g.wgs = best;
     g.envs_per_wg = best / N;
