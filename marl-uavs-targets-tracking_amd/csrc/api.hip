@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -45,7 +46,7 @@ void free_state(uavtrack_env *env)
 {
     StateBlock &s = env->state;
     void *ptrs[] = {s.ux, s.uy, s.uz, s.uh, s.ua, s.tx, s.ty, s.tz, s.th, s.step_count,
-                    env->d_state, env->pmi.blob, env->pairs, env->pair_count, env->pair_total, env->scores, env->raw,
+                    env->d_state, env->pmi.blob, env->pairs, env->pair_count, env->pair_total, env->scores, env->pose,
                     env->obs_tmp, env->terms_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -68,6 +69,45 @@ int validate(const uavtrack_config &c)
     if (c.horizon < 0) return fail("horizon must be >= 0");
     if (!(c.dc > 0) || !(c.dp > 0) || !(c.u_v_max > 0) || !(c.dt > 0)) return fail("dc, dp, u_v_max, dt must be > 0");
     if ((int64_t)c.n_envs * c.n_uav * UAVTRACK_OBS_DIM > ((int64_t)1 << 40)) return fail("batch too large");
+    return 0;
+}
+
+// MAAC-R scratch for deferred scoring of up to `steps` steps per chunk (grow-only).  Per step: the pair
+// list at its worst case (every pair within dp), the dense score matrix, pose/raw, and observation /
+// term buffers for callers that pass NULL.  UAVTRACK_PMI_SCRATCH_MB bounds it (default 2048 MiB).
+int ensure_pmi_scratch(uavtrack_env *env, int32_t steps, hipStream_t st)
+{
+    const uavtrack_config &c = env->cfg;
+    const size_t BN = (size_t)c.n_envs * c.n_uav;
+    const size_t pairs_step = BN * (c.n_uav - 1) / 2 + 1;
+    const size_t per_step = pairs_step * sizeof(uint2) + BN * c.n_uav * 4 + BN * 16 + BN * UAVTRACK_OBS_DIM * 4 + 3 * BN * 4;
+    size_t budget = (size_t)2048 << 20;
+    if (const char *s = getenv("UAVTRACK_PMI_SCRATCH_MB")) budget = (size_t)atoll(s) << 20;
+    int64_t cap = (int64_t)(budget / per_step);
+    const int64_t idx_cap = (int64_t)(0xFFFFFFFFull / BN);     // pair records carry a 32-bit flat [step][b][i] index
+    if (cap > idx_cap) cap = idx_cap;
+    if (cap < 1) cap = 1;
+    if (cap > steps) cap = steps;
+    if (cap <= env->pmi_steps_cap) return 0;
+    HIP_TRY(hipStreamSynchronize(st));
+    void *old[] = {env->pairs, env->scores, env->pose, env->obs_tmp, env->terms_tmp};
+    for (void *q : old)
+        if (q) (void)hipFree(q);
+    env->pairs = nullptr; env->scores = nullptr; env->pose = nullptr; env->obs_tmp = nullptr; env->terms_tmp = nullptr;
+    env->pmi_steps_cap = 0;
+    const size_t S = (size_t)cap;
+    HIP_TRY(dmalloc(&env->pairs, S * pairs_step));
+    HIP_TRY(dmalloc(&env->scores, S * BN * c.n_uav));
+    HIP_TRY(dmalloc(&env->pose, S * BN));
+    HIP_TRY(dmalloc(&env->obs_tmp, S * BN * UAVTRACK_OBS_DIM));
+    HIP_TRY(dmalloc(&env->terms_tmp, S * 3 * BN));
+    if (!env->pair_count) {
+        HIP_TRY(dmalloc(&env->pair_count, 1));
+        HIP_TRY(hipMemsetAsync(env->pair_count, 0, sizeof(unsigned), st));
+        HIP_TRY(dmalloc(&env->pair_total, 1));
+        HIP_TRY(hipMemsetAsync(env->pair_total, 0, sizeof(unsigned long long), st));
+    }
+    env->pmi_steps_cap = (int32_t)cap;
     return 0;
 }
 
@@ -289,21 +329,7 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
     }
     env->pmi.hidden = hidden;
     env->pmi.n_floats = n_floats;
-    if (!env->pairs) {   // MAAC-R scratch, sized for the worst case (every pair within dp)
-        const uavtrack_config &c = env->cfg;
-        const size_t BN = (size_t)c.n_envs * c.n_uav;
-        const size_t max_pairs = (size_t)c.n_envs * c.n_uav * (c.n_uav - 1) / 2;
-        HIP_TRY(dmalloc(&env->pairs, max_pairs));
-        HIP_TRY(dmalloc(&env->pair_count, 1));
-        HIP_TRY(hipMemsetAsync(env->pair_count, 0, sizeof(unsigned), st));
-        HIP_TRY(dmalloc(&env->pair_total, 1));
-        HIP_TRY(hipMemsetAsync(env->pair_total, 0, sizeof(unsigned long long), st));
-        HIP_TRY(dmalloc(&env->scores, BN * c.n_uav));
-        HIP_TRY(dmalloc(&env->raw, BN));
-        HIP_TRY(dmalloc(&env->obs_tmp, BN * UAVTRACK_OBS_DIM));
-        HIP_TRY(dmalloc(&env->terms_tmp, 3 * BN));
-        HIP_TRY(hipMemsetAsync(env->scores, 0, BN * c.n_uav * sizeof(float), st));
-    }
+    if (ensure_pmi_scratch(env, 1, st)) return 1;
     return 0;
 }
 
@@ -319,7 +345,7 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
     hipStream_t st = static_cast<hipStream_t>(stream);
     StepParams p = env->base;
     p.actions = actions;
-    p.obs = obs; p.reward = reward; p.terms = terms; p.raw_out = nullptr;
+    p.obs = obs; p.reward = reward; p.terms = terms; p.pose_out = nullptr;
     p.covered = covered; p.done = done; p.ep_sums = ep_sums;
     p.pairs = nullptr; p.pair_count = nullptr;
     p.ep_accumulate = accumulate ? 1 : 0;
@@ -328,29 +354,37 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
         HIP_TRY(launch_rollout(env, p, st));
         return 0;
     }
-    // MAAC-R: per step, the fused kernel (observations, raw rewards, neighbour pair list), the
-    // MFMA pair scorer, and the softmax mix; everything stream-ordered, nothing on the host.
+    // MAAC-R.  Rewards never feed back into the dynamics, so scoring is deferred: a chunk of steps is
+    // simulated by ONE fused launch (observations, raw rewards, poses, and the neighbour pairs of every
+    // step of the chunk), then ONE launch of the MFMA scorer over all those pairs, then ONE launch of the
+    // softmax mix.  T = 1 (closed loop) is a chunk of one.  Everything is stream-ordered.
     if (!env->pmi.blob) return fail("%s: reward_mode PMI needs uavtrack_set_pmi_weights first", who);
+    if (ensure_pmi_scratch(env, T, st)) return 1;
     const uavtrack_config &c = env->cfg;
     const size_t BN = (size_t)c.n_envs * c.n_uav;
-    if (ep_sums && !accumulate) HIP_TRY(hipMemsetAsync(ep_sums, 0, (size_t)c.n_envs * 5 * sizeof(float), st));
-    p.T = 1;
     p.ep_sums = nullptr;
-    p.raw_out = env->raw;
+    p.pose_out = env->pose;
     p.pairs = env->pairs;
-    p.pair_count = env->pair_count;
-    for (int32_t t = 0; t < T; ++t) {
-        float *obs_t = obs ? obs + (size_t)t * BN * UAVTRACK_OBS_DIM : env->obs_tmp;
-        float *terms_t = terms ? terms + (size_t)t * 3 * BN : (ep_sums ? env->terms_tmp : nullptr);
-        float *reward_t = reward + (size_t)t * BN;
-        int32_t *covered_t = covered ? covered + (size_t)t * c.n_envs : nullptr;
-        p.actions = actions + (size_t)t * BN;
+    p.pair_count = env->pair_count;      // zero: set at allocation, re-zeroed by the mix kernel
+    bool add = accumulate;
+    for (int32_t t0 = 0; t0 < T; t0 += env->pmi_steps_cap) {
+        const int32_t n = (T - t0 < env->pmi_steps_cap) ? T - t0 : env->pmi_steps_cap;
+        float *obs_t = obs ? obs + (size_t)t0 * BN * UAVTRACK_OBS_DIM : env->obs_tmp;
+        float *terms_t = terms ? terms + (size_t)t0 * 3 * BN : (ep_sums ? env->terms_tmp : nullptr);
+        float *reward_t = reward + (size_t)t0 * BN;
+        int32_t *covered_t = covered ? covered + (size_t)t0 * c.n_envs : nullptr;
+        p.T = n;
+        p.actions = actions + (size_t)t0 * BN;
         p.obs = obs_t; p.reward = reward_t; p.terms = terms_t;
         p.covered = covered_t;
-        p.done = done ? done + (size_t)t * c.n_envs : nullptr;
-        HIP_TRY(launch_rollout(env, p, st));   // pair_count is zero: set at allocation, re-zeroed by the finalize kernel
+        p.done = done ? done + (size_t)t0 * c.n_envs : nullptr;
+        HIP_TRY(launch_rollout(env, p, st));
         HIP_TRY(launch_pmi_score(env, obs_t, st));
-        HIP_TRY(launch_pmi_finalize(env, reward_t, terms_t, covered_t, ep_sums, st));
+        HIP_TRY(launch_pmi_finalize(env, n, reward_t, st));
+        if (ep_sums) {
+            HIP_TRY(launch_ep_sums(env, n, reward_t, terms_t, covered_t, ep_sums, add, st));
+            add = true;
+        }
     }
     return 0;
 }

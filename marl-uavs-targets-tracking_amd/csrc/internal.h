@@ -30,11 +30,12 @@ struct StepParams {
     const StateBlock *st;
     // per-step I/O, leading [T] axis
     const int32_t *actions;
-    float *obs, *reward, *terms, *raw_out;
+    float *obs, *reward, *terms;
+    float4 *pose_out;        // MAAC-R: (x, y, z, raw reward) per agent-step, read by the deferred softmax mix
     int32_t *covered;
     uint8_t *done;
     float *ep_sums;
-    uint2 *pairs;            // MAAC-R: neighbour pair list {flat agent index of i, j}, i < j
+    uint2 *pairs;            // MAAC-R: neighbour pair list {flat [t][b][i] index of i, j}, i < j
     unsigned *pair_count;
     // geometry
     int32_t B, N, M, E, T, na, na_total, horizon;
@@ -75,14 +76,16 @@ struct uavtrack_env {
     uavtrack::StateBlock *d_state = nullptr;
     uavtrack::Geometry geo;
     uavtrack::PmiWeights pmi;
-    // MAAC-R scratch, allocated with the weights: pair list + counter, dense score matrix
-    // [B][N][N], raw reward [B][N], and an observation buffer for callers that pass obs = NULL
-    void *pmi_scratch = nullptr;
-    size_t pmi_scratch_bytes = 0;
+    // MAAC-R scratch for `pmi_steps_cap` steps of deferred scoring (rewards never feed back into the
+    // dynamics, so a chunk of steps is simulated first and all its pairs are scored in one launch):
+    // pair list + counter, dense score matrix [steps][B][N][N], pose/raw [steps][B][N], and
+    // observation / term buffers for callers that pass NULL
+    int32_t pmi_steps_cap = 0;
     uint2 *pairs = nullptr;
     unsigned *pair_count = nullptr;
     unsigned long long *pair_total = nullptr;
-    float *scores = nullptr, *raw = nullptr, *obs_tmp = nullptr, *terms_tmp = nullptr;
+    float *scores = nullptr, *obs_tmp = nullptr, *terms_tmp = nullptr;
+    float4 *pose = nullptr;
 };
 
 namespace uavtrack {
@@ -95,8 +98,9 @@ hipError_t launch_rollout(const uavtrack_env *env, const StepParams &p, hipStrea
 bool pmi_hidden_supported(int hidden);
 void pack_pmi_blob(const float *abi_blob, float *device_order, int hidden);
 hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream_t stream);
-hipError_t launch_pmi_finalize(const uavtrack_env *env, float *reward, const float *terms, const int32_t *covered,
-                               float *ep_sums, hipStream_t stream);
+hipError_t launch_pmi_finalize(const uavtrack_env *env, int steps, float *reward, hipStream_t stream);
+hipError_t launch_ep_sums(const uavtrack_env *env, int steps, const float *reward, const float *terms,
+                          const int32_t *covered, float *ep_sums, bool add, hipStream_t stream);
 
 // reset_kernel.hip
 hipError_t launch_reset(const uavtrack_env *env, uint64_t seed, uint32_t episode, float *obs,

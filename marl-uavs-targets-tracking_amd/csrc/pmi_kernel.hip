@@ -33,10 +33,10 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct PmiParams {
     const float *blob;       // folded weights, layout of uavtrack_set_pmi_weights
-    const float *obs;        // [B][N][12] local states of this step
-    const uint2 *pairs;      // {flat agent index of i, j}
+    const float *obs;        // [S][B][N][12] local states of the chunk's steps
+    const uint2 *pairs;      // {flat [step][b][i] index of i within the chunk, j}
     const unsigned *pair_count;
-    float *scores;           // [B][N][N]
+    float *scores;           // [S][B][N][N]
     unsigned long long *pair_total;
     int32_t N;
 };
@@ -180,95 +180,110 @@ __global__ void __launch_bounds__(H * 2) pmi_score_kernel(const PmiParams q)
 }
 
 struct FinalizeParams {
-    const float *ux, *uy, *uz;
-    const float *raw, *scores;
-    float *reward;
-    const float *terms;          // [3][B][N] of this step (nullable)
-    const int32_t *covered;      // [B] of this step (nullable)
-    float *ep_sums;              // [B][5] running episode accumulators (nullable)
-    unsigned *pair_count;        // reset here for the next step's pair emission
-    int32_t B, N, E, three_d;
+    const float4 *pose;          // [S][B][N] (x, y, z, raw) of the chunk's S steps
+    const float *scores;         // [S][B][N][N]
+    float *reward;               // [S][B][N]
+    unsigned *pair_count;        // reset here for the next chunk's pair emission
+    int32_t SB, N, E, three_d;   // SB = S * B "virtual environments"
     float dp2, coop;
 };
 
-// One lane per UAV, E whole environments per workgroup (same geometry as the step kernel).
-// Poses and raw rewards of the workgroup's environments are staged in LDS; every lane walks
-// its row of the score matrix with unconditional, independent loads.
+// One lane per UAV-step, E whole (step, environment) instances per workgroup (the step kernel's
+// geometry over S*B instances).  Poses and raw rewards of the workgroup's instances are staged in
+// LDS; every lane walks its row of the score matrix with unconditional, independent loads.
 __global__ void __launch_bounds__(kMaxWorkgroup) pmi_finalize_kernel(const FinalizeParams f)
 {
     extern __shared__ float4 fin4[];
     float4 *pose = fin4;                                        // [E*N] (x, y, z, raw)
-    float *red = reinterpret_cast<float *>(fin4 + f.E * f.N);   // [E*N][4] reward + 3 terms, for ep_sums
     const int tid = threadIdx.x;
     const int N = f.N;
     const int env0 = blockIdx.x * f.E;
-    const int envs_here = min(f.E, f.B - env0);
+    const int envs_here = min(f.E, f.SB - env0);
     const int e = tid / N, i = tid - e * N;
     const bool active = tid < f.E * N && e < envs_here;
     const size_t gid = (size_t)(env0 + e) * N + i;
     if (blockIdx.x == 0 && tid == 0) *f.pair_count = 0;
-    float x = 0, y = 0, z = 0, raw_i = 0;
+    float4 me = make_float4(0, 0, 0, 0);
     if (active) {
-        x = f.ux[gid]; y = f.uy[gid]; raw_i = f.raw[gid];
-        if (f.three_d) z = f.uz[gid];
-        pose[tid] = make_float4(x, y, z, raw_i);
+        me = f.pose[gid];
+        pose[tid] = me;
     }
     __syncthreads();
-    float r = 0;
-    if (active) {
-        const float *srow = f.scores + gid * N;
-        const float4 *pe = pose + e * N;
-        // pass 1: max score over neighbours (same d2 expression as the pair emission in the step kernel)
-        float mx = -INFINITY;
-        int cnt = 0;
+    if (!active) return;
+    const float x = me.x, y = me.y, z = me.z, raw_i = me.w;
+    const float *srow = f.scores + gid * N;
+    const float4 *pe = pose + e * N;
+    // pass 1: max score over neighbours (dist2() of step_kernel.hip: the pair emission's expression)
+    float mx = -INFINITY;
+    int cnt = 0;
+    for (int j = 0; j < N; ++j) {
+        const float4 pj = pe[j];
+        const float sj = srow[j];
+        float d2 = fmaf(pj.y - y, pj.y - y, (pj.x - x) * (pj.x - x));
+        if (f.three_d) { const float dz = pj.z - z; d2 = fmaf(dz, dz, d2); }
+        const bool nb = j != i && d2 <= f.dp2;
+        mx = nb ? fmaxf(mx, sj) : mx;
+        cnt += nb ? 1 : 0;
+    }
+    float r = (1.0f - f.coop) * raw_i;                                 // uav.py:290
+    if (cnt) {
+        float den = 0.0f, num = 0.0f;
         for (int j = 0; j < N; ++j) {
             const float4 pj = pe[j];
             const float sj = srow[j];
-            float d2 = fmaf(pj.y - y, pj.y - y, (pj.x - x) * (pj.x - x));    // dist2() of step_kernel.hip
+            float d2 = fmaf(pj.y - y, pj.y - y, (pj.x - x) * (pj.x - x));
             if (f.three_d) { const float dz = pj.z - z; d2 = fmaf(dz, dz, d2); }
-            const bool nb = j != i && d2 <= f.dp2;
-            mx = nb ? fmaxf(mx, sj) : mx;
-            cnt += nb ? 1 : 0;
-        }
-        r = (1.0f - f.coop) * raw_i;                                 // uav.py:290
-        if (cnt) {
-            float den = 0.0f, num = 0.0f;
-            for (int j = 0; j < N; ++j) {
-                const float4 pj = pe[j];
-                const float sj = srow[j];
-                float d2 = fmaf(pj.y - y, pj.y - y, (pj.x - x) * (pj.x - x));
-                if (f.three_d) { const float dz = pj.z - z; d2 = fmaf(dz, dz, d2); }
-                if (j != i && d2 <= f.dp2) {                         // scipy softmax, uav.py:287
-                    const float ew = expf(sj - mx);
-                    den += ew;
-                    num = fmaf(ew, pj.w, num);
-                }
+            if (j != i && d2 <= f.dp2) {                             // scipy softmax, uav.py:287
+                const float ew = expf(sj - mx);
+                den += ew;
+                num = fmaf(ew, pj.w, num);
             }
-            r = fmaf(f.coop, num / den, r);                          // uav.py:288
         }
-        r = fminf(fmaxf(r, -1.0f), 1.0f);                            // environment.py:225
-        f.reward[gid] = r;
+        r = fmaf(f.coop, num / den, r);                              // uav.py:288
     }
-    if (f.ep_sums) {                                                 // train.py:181-192 accumulators
-        const size_t BN = (size_t)f.B * N;
-        if (active) {
-            red[tid * 4 + 0] = r;
-            red[tid * 4 + 1] = f.terms ? f.terms[gid] : 0.0f;
-            red[tid * 4 + 2] = f.terms ? f.terms[BN + gid] : 0.0f;
-            red[tid * 4 + 3] = f.terms ? f.terms[2 * BN + gid] : 0.0f;
-        }
-        __syncthreads();
-        if (active && i == 0) {
-            float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-            for (int j = 0; j < N; ++j) {                            // fixed order
-                const float *q = red + (e * N + j) * 4;
-                s0 += q[0]; s1 += q[1]; s2 += q[2]; s3 += q[3];
+    f.reward[gid] = fminf(fmaxf(r, -1.0f), 1.0f);                    // environment.py:225
+}
+
+// train.py:181-192 accumulators for the MAAC-R path, from the chunk's outputs (the fused kernel keeps
+// them in registers for the other reward modes).  One lane per UAV, fixed-order reductions.
+struct EpParams {
+    const float *reward, *terms;     // [S][B][N], [S][3][B][N] (terms nullable)
+    const int32_t *covered;          // [S][B] (nullable)
+    float *ep_sums;                  // [B][5]
+    int32_t S, B, N, E, add;
+};
+
+__global__ void __launch_bounds__(kMaxWorkgroup) ep_sums_kernel(const EpParams q)
+{
+    extern __shared__ float4 red4[];
+    const int tid = threadIdx.x, N = q.N;
+    const int env0 = blockIdx.x * q.E;
+    const int envs_here = min(q.E, q.B - env0);
+    const int e = tid / N, i = tid - e * N;
+    const bool active = tid < q.E * N && e < envs_here;
+    const size_t BN = (size_t)q.B * N, g = (size_t)(env0 + e) * N + i;
+    float4 acc = make_float4(0, 0, 0, 0);
+    if (active) {
+        for (int t = 0; t < q.S; ++t) {
+            acc.x += q.reward[(size_t)t * BN + g];
+            if (q.terms) {
+                const float *tp = q.terms + (size_t)t * 3 * BN + g;
+                acc.y += tp[0]; acc.z += tp[BN]; acc.w += tp[2 * BN];
             }
-            const float inv = 1.0f / (float)N;
-            float *ep = f.ep_sums + (size_t)(env0 + e) * 5;
-            ep[0] += s0 * inv; ep[1] += s1 * inv; ep[2] += s2 * inv; ep[3] += s3 * inv;
-            if (f.covered) ep[4] += (float)f.covered[env0 + e];
         }
+        red4[tid] = acc;
+    }
+    __syncthreads();
+    if (active && i == 0) {
+        float4 s = make_float4(0, 0, 0, 0);
+        for (int j = 0; j < N; ++j) { const float4 v = red4[e * N + j]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        float cov = 0.0f;
+        if (q.covered)
+            for (int t = 0; t < q.S; ++t) cov += (float)q.covered[(size_t)t * q.B + env0 + e];
+        const float inv = 1.0f / (float)N;
+        float *ep = q.ep_sums + (size_t)(env0 + e) * 5;
+        if (q.add) { ep[0] += s.x * inv; ep[1] += s.y * inv; ep[2] += s.z * inv; ep[3] += s.w * inv; ep[4] += cov; }
+        else       { ep[0] = s.x * inv;  ep[1] = s.y * inv;  ep[2] = s.z * inv;  ep[3] = s.w * inv;  ep[4] = cov; }
     }
 }
 
@@ -317,19 +332,27 @@ hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream
     return hipGetLastError();
 }
 
-hipError_t launch_pmi_finalize(const uavtrack_env *env, float *reward, const float *terms, const int32_t *covered,
-                               float *ep_sums, hipStream_t stream)
+hipError_t launch_pmi_finalize(const uavtrack_env *env, int steps, float *reward, hipStream_t stream)
 {
     const uavtrack_config &c = env->cfg;
     FinalizeParams f;
-    f.ux = env->state.ux; f.uy = env->state.uy; f.uz = env->state.uz;
-    f.raw = env->raw; f.scores = env->scores; f.reward = reward;
-    f.terms = terms; f.covered = covered; f.ep_sums = ep_sums;
+    f.pose = env->pose; f.scores = env->scores; f.reward = reward;
     f.pair_count = env->pair_count;
-    f.B = c.n_envs; f.N = c.n_uav; f.E = env->geo.envs_per_wg; f.three_d = c.dim == 3;
+    f.SB = steps * c.n_envs; f.N = c.n_uav; f.E = env->geo.envs_per_wg; f.three_d = c.dim == 3;
     f.dp2 = env->base.dp2; f.coop = env->base.coop;
-    const size_t lds = (size_t)f.E * f.N * (16 + 16);
-    hipLaunchKernelGGL(pmi_finalize_kernel, dim3(env->geo.groups), dim3(env->geo.wgs), lds, stream, f);
+    const unsigned groups = (unsigned)((f.SB + f.E - 1) / f.E);
+    const size_t lds = (size_t)f.E * f.N * 16;
+    hipLaunchKernelGGL(pmi_finalize_kernel, dim3(groups), dim3(env->geo.wgs), lds, stream, f);
+    return hipGetLastError();
+}
+
+hipError_t launch_ep_sums(const uavtrack_env *env, int steps, const float *reward, const float *terms,
+                          const int32_t *covered, float *ep_sums, bool add, hipStream_t stream)
+{
+    const uavtrack_config &c = env->cfg;
+    EpParams q{reward, terms, covered, ep_sums, steps, c.n_envs, c.n_uav, env->geo.envs_per_wg, add ? 1 : 0};
+    const size_t lds = (size_t)q.E * q.N * 16;
+    hipLaunchKernelGGL(ep_sums_kernel, dim3(env->geo.groups), dim3(env->geo.wgs), lds, stream, q);
     return hipGetLastError();
 }
 

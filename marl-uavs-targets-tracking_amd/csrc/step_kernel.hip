@@ -574,7 +574,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                 op[2] = make_float4(o[8], o[9], o[10], o[11]);
             }
             if (p.reward) p.reward[tg_off] = r;
-            if (p.raw_out) p.raw_out[tg_off] = raw;
+            if (p.pose_out) p.pose_out[tg_off] = make_float4(x, y, z, raw);
             if (p.terms) {
                 float *tp = p.terms + (size_t)t * 3 * BN + g;   // [t][3][b][i]
                 tp[0] = tt;
@@ -610,7 +610,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                     const UavRow nw = uav_elem(rowNew, j);
                     float d2 = dist2(nw.x - x, nw.y - y);
                     if (Z3) { const float dz = nw.z - z; d2 = fmaf(dz, dz, d2); }
-                    if (d2 <= p.dp2) *dst++ = make_uint2((unsigned)g, (unsigned)j);
+                    if (d2 <= p.dp2) *dst++ = make_uint2((unsigned)tg_off, (unsigned)j);
                 }
             }
         }
