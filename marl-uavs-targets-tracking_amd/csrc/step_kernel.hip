@@ -165,13 +165,14 @@ __device__ __forceinline__ void uav_store(float4 *rows, int j, float x, float y,
 // Pair sweeps of one UAV, fast path: two agents per packed instruction, no per-agent
 // `j != i` test (self terms are subtracted afterwards).  The uav.py:165/179 weight is 1
 // here (see sweep_weighted).
-template <int N_, int M_, bool Z3>
+template <int N_, int M_, bool Z3, bool NB>
 __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, int i,
                                            const float4 *__restrict__ rowNew, const float4 *__restrict__ rowOld,
                                            const float4 *__restrict__ trow, const v2f *__restrict__ tzrow,
                                            unsigned *__restrict__ covw, int covbase,
                                            float xi, float yi, float zi, float ci, float si, float ai,
-                                           float xo, float yo, float zo, float co, float so, float ao, Acc &a)
+                                           float xo, float yo, float zo, float co, float so, float ao, Acc &a,
+                                           unsigned long long &nbmask)
 {
     const v2f xi2 = splat(xi), yi2 = splat(yi), zi2 = splat(zi);
     const int NP = pairs_of(N_ > 0 ? N_ : N), MP = pairs_of(M_ > 0 ? M_ : M);
@@ -227,6 +228,8 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
             d2n = pk_fma(dzn, dzn, d2n);
             d2m = pk_fma(dzm, dzm, d2m);
         }
+        if (NB)   // MAAC-R (N <= 64): neighbours (d <= dp on post-move poses, uav.py:278) as a bit mask
+            nbmask |= ((unsigned long long)(d2n.x <= p.dp2 ? 1u : 0u) | (unsigned long long)(d2n.y <= p.dp2 ? 2u : 0u)) << (2 * jp);
         const v2f w = pk_fma((v2f){fast_sqrt(d2n.x), fast_sqrt(d2n.y)}, splat(-p.exp_k1), splat(p.exp_k0));
         dup += (v2f){d2n.x <= p.two_dp2 ? fast_exp2(w.x) : 0.0f, d2n.y <= p.two_dp2 ? fast_exp2(w.y) : 0.0f};
         const v2f mm = {d2m.x <= p.dc2 ? 1.0f : 0.0f, d2m.y <= p.dc2 ? 1.0f : 0.0f};
@@ -480,16 +483,26 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         const float4 *rowNew = uenv + pn * 3;
         const float4 *rowOld = uenv + (pn ^ 1) * 3;
         const v2f *tzrow = reinterpret_cast<const v2f *>(tzf + e * MP * 2);
+        constexpr bool kMask = (MODE == UAVTRACK_REWARD_PMI) && N_ > 0 && N_ <= 64;   // neighbour set fits one mask
+        unsigned long long nbmask = 0;
         if (active) {
             Acc acc;
             // weight of uav.py:165 can be < 1 only near the origin; wave-uniform branch
             const bool near0 = fabsf(x) < 2.5f && fabsf(y) < 2.5f;
-            if (__builtin_expect(__any(near0), 0))
+            if (__builtin_expect(__any(near0), 0)) {
                 sweep_weighted<Z3>(p, N, M, i, rowNew, rowOld, tenv, tzrow, covw, cbuf + e * CW,
                                    x, y, z, c, s, ai, acc);
-            else
-                sweep_fast<N_, M_, Z3>(p, N, M, i, rowNew, rowOld, tenv, tzrow, covw, cbuf + e * CW,
-                                       x, y, z, c, s, ai, xo, yo, zo, co, so, ao, acc);
+                if (kMask)
+                    for (int j = 0; j < N; ++j) {
+                        const UavRow nw = uav_elem(rowNew, j);
+                        float d2 = dist2(nw.x - x, nw.y - y);
+                        if (Z3) { const float dz = nw.z - z; d2 = fmaf(dz, dz, d2); }
+                        nbmask |= (unsigned long long)(d2 <= p.dp2 ? 1u : 0u) << j;
+                    }
+            } else {
+                sweep_fast<N_, M_, Z3, kMask>(p, N, M, i, rowNew, rowOld, tenv, tzrow, covw, cbuf + e * CW,
+                                              x, y, z, c, s, ai, xo, yo, zo, co, so, ao, acc, nbmask);
+            }
 
             // ---- P3: local state (uav.py:156-190)
             if (acc.cntU > 0.0f) {
@@ -592,12 +605,18 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             if (tid == 0) wg_cnt[0] = 0;
             __syncthreads();
             int mine = 0, slot = 0;
+            unsigned long long later = 0;                   // neighbours j > i
             if (active) {
-                for (int j = i + 1; j < N; ++j) {
-                    const UavRow nw = uav_elem(rowNew, j);
-                    float d2 = dist2(nw.x - x, nw.y - y);
-                    if (Z3) { const float dz = nw.z - z; d2 = fmaf(dz, dz, d2); }
-                    mine += (d2 <= p.dp2) ? 1 : 0;
+                if (kMask) {
+                    later = (i + 1 < 64) ? (nbmask >> (i + 1)) << (i + 1) : 0ull;
+                    mine = __popcll(later);
+                } else {
+                    for (int j = i + 1; j < N; ++j) {
+                        const UavRow nw = uav_elem(rowNew, j);
+                        float d2 = dist2(nw.x - x, nw.y - y);
+                        if (Z3) { const float dz = nw.z - z; d2 = fmaf(dz, dz, d2); }
+                        mine += (d2 <= p.dp2) ? 1 : 0;
+                    }
                 }
                 if (mine) slot = (int)atomicAdd(&wg_cnt[0], (unsigned)mine);
             }
@@ -606,11 +625,19 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             __syncthreads();
             if (active && mine) {
                 uint2 *dst = p.pairs + wg_cnt[1] + slot;
-                for (int j = i + 1; j < N; ++j) {
-                    const UavRow nw = uav_elem(rowNew, j);
-                    float d2 = dist2(nw.x - x, nw.y - y);
-                    if (Z3) { const float dz = nw.z - z; d2 = fmaf(dz, dz, d2); }
-                    if (d2 <= p.dp2) *dst++ = make_uint2((unsigned)tg_off, (unsigned)j);
+                if (kMask) {
+                    while (later) {                          // ascending j
+                        const int j = __ffsll((long long)later) - 1;
+                        later &= later - 1;
+                        *dst++ = make_uint2((unsigned)tg_off, (unsigned)j);
+                    }
+                } else {
+                    for (int j = i + 1; j < N; ++j) {
+                        const UavRow nw = uav_elem(rowNew, j);
+                        float d2 = dist2(nw.x - x, nw.y - y);
+                        if (Z3) { const float dz = nw.z - z; d2 = fmaf(dz, dz, d2); }
+                        if (d2 <= p.dp2) *dst++ = make_uint2((unsigned)tg_off, (unsigned)j);
+                    }
                 }
             }
         }
