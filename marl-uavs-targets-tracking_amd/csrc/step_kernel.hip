@@ -87,20 +87,12 @@ __device__ __forceinline__ int xcd_group(int bid, int nwg)
 // spending mantissa bits when no wrap is needed.
 __device__ __forceinline__ float wrap_heading(float h)
 {
-    if (h >= kPi) {
-        h -= kTwoPi;
-        if (h >= kPi) {   // far out of range (injected state): general reduction
-            float t = h + kPi;
-            t -= kTwoPi * floorf(t * (1.0f / kTwoPi));
-            h = t - kPi;
-        }
-    } else if (h < -kPi) {
-        h += kTwoPi;
-        if (h < -kPi) {
-            float t = h + kPi;
-            t -= kTwoPi * floorf(t * (1.0f / kTwoPi));
-            h = t - kPi;
-        }
+    // one turn step from a wrapped heading stays within (-pi - pi/6, pi + pi/6): branch-free single fold
+    h = (h >= kPi) ? h - kTwoPi : ((h < -kPi) ? h + kTwoPi : h);
+    if (__builtin_expect(fabsf(h) > kPi, 0)) {   // far out of range (injected state): general reduction
+        float t = h + kPi;
+        t -= kTwoPi * floorf(t * (1.0f / kTwoPi));
+        h = t - kPi;
     }
     return h;
 }
