@@ -42,20 +42,19 @@ struct PmiParams {
 };
 
 template <int H>
-__global__ void __launch_bounds__(H * 2) pmi_score_kernel(const PmiParams q)
+__global__ void __launch_bounds__(H * 2, 2) pmi_score_kernel(const PmiParams q)
 {
     constexpr int K = 3 * H;             // fc1 input width
     constexpr int KH = K / 2;            // MFMA k-steps (32x32x2)
     constexpr int ROW = KH + 4;          // padded LDS row: 32 rows of one k-parity never share a bank slot
     constexpr int NW = H / 32;           // wavefronts = column blocks
-    constexpr int NT = NW * 64;          // threads
-    constexpr int GROUPS = NT / 32;      // threads per pair in the branch layers
-    constexpr int PER = H / GROUPS;      // outputs per thread per branch
+    constexpr int NT = NW * 64;          // threads = 2 H
+    constexpr int PPT = 32 / (NT / H);   // pairs per thread in the branch layers (16)
 
-    __shared__ float4 lds4[(2 * 32 * ROW + 12 * H + 3 * H + NW * 32) / 4 + 2];
+    __shared__ float4 lds4[(2 * 32 * ROW + 2 * 32 * 12 + 2 * NW * 32) / 4 + 2];
     float *h0s = reinterpret_cast<float *>(lds4);          // [2][32][ROW]  (k parity, pair, k/2)
-    float *wa = h0s + 2 * 32 * ROW;                        // Wc[5][H] bc[H] Wo[4][H] bo[H] Wb[3][H] bb[H]
-    float *part = wa + 15 * H;                             // [NW][32] per-column-block partial scores
+    float *xs = h0s + 2 * 32 * ROW;                        // [2 tiles][32 pairs][12]  x = la_i * la_j
+    float *part = xs + 2 * 32 * 12;                        // [2 tiles][NW][32] per-column-block partial scores
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -79,21 +78,37 @@ __global__ void __launch_bounds__(H * 2) pmi_score_kernel(const PmiParams q)
         breg[4 * t4 + 0] = v.x; breg[4 * t4 + 1] = v.y; breg[4 * t4 + 2] = v.z; breg[4 * t4 + 3] = v.w;
     }
     const float bias1 = b1[col], wout = w2[col];
-    for (int k = tid; k < 15 * H; k += NT) wa[k] = q.blob[k];
-    __syncthreads();
+    // Branch layers (PMINet.py:50-55): thread (o, half) owns output o of each of the three branches for
+    // 16 of the tile's 32 pairs; its 15 folded weights stay in registers, only the pair inputs come
+    // from LDS (three broadcast ds_read_b128 per pair).
+    const int o = tid % H, phalf = tid / H;
+    float wc[5], wo[4], wb[3];
+#pragma unroll
+    for (int v = 0; v < 5; ++v) wc[v] = q.blob[v * H + o];
+    const float bc = q.blob[5 * H + o];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) wo[v] = q.blob[6 * H + v * H + o];
+    const float bo = q.blob[10 * H + o];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) wb[v] = q.blob[11 * H + v * H + o];
+    const float bb = q.blob[14 * H + o];
+    // where this thread's three outputs live in the activation tile: concat order (PMINet.py:58)
+    // comm | obs | boundary_state; k -> (parity k & 1, step k >> 1)
+    const int k0 = o, k1 = H + o, k2 = 2 * H + o;
+    float *const hc0 = h0s + ((k0 & 1) * 32) * ROW + (k0 >> 1);
+    float *const hc1 = h0s + ((k1 & 1) * 32) * ROW + (k1 >> 1);
+    float *const hc2 = h0s + ((k2 & 1) * 32) * ROW + (k2 >> 1);
 
     const unsigned npairs = *q.pair_count;
     const unsigned ntiles = (npairs + 31) >> 5;
     if (blockIdx.x == 0 && tid == 0) *q.pair_total += npairs;      // accounting only (one writer)
-    const int p = tid & 31;              // pair of this thread in the branch layers
-    const int grp = tid >> 5;            // which slice of the H outputs of each branch
 
-    // gather of one tile: pair record + x = la_i * la_j (uav.py:281).  Issued one tile ahead so that
-    // the loads fly under the previous tile's MFMA phase.
-    auto gather = [&](unsigned tile, uint2 &pr, float (&x)[12]) {
-        const unsigned pi = tile * 32 + p;
+    // gather of one pair by the first 32 threads: pair record + x = la_i * la_j (uav.py:281)
+    auto gather = [&](unsigned tile, uint2 &pr, float4 (&x)[3]) {
+        const unsigned pi = tile * 32 + tid;
         pr = make_uint2(0, 0);
-        if (tile < ntiles && pi < npairs) {
+        x[0] = x[1] = x[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < 32 && tile < ntiles && pi < npairs) {
             pr = q.pairs[pi];
             const unsigned gi = pr.x, gj = (pr.x / q.N) * q.N + pr.y;
             const float4 *oi = reinterpret_cast<const float4 *>(q.obs + (size_t)gi * 12);
@@ -101,45 +116,54 @@ __global__ void __launch_bounds__(H * 2) pmi_score_kernel(const PmiParams q)
 #pragma unroll
             for (int v = 0; v < 3; ++v) {
                 const float4 a = oi[v], b = oj[v];
-                x[4 * v + 0] = a.x * b.x; x[4 * v + 1] = a.y * b.y;
-                x[4 * v + 2] = a.z * b.z; x[4 * v + 3] = a.w * b.w;
+                x[v] = make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
             }
-        } else {
-#pragma unroll
-            for (int v = 0; v < 12; ++v) x[v] = 0.0f;
         }
     };
 
-    uint2 pr_next;
-    float x_next[12];
-    gather(blockIdx.x, pr_next, x_next);
-
-    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        // ---- branch layers (PMINet.py:50-55) on the prefetched inputs
-        const uint2 pr = pr_next;
-        float x[12];
-#pragma unroll
-        for (int v = 0; v < 12; ++v) x[v] = x_next[v];
-#pragma unroll
-        for (int m = 0; m < PER; ++m) {
-            const int o = grp + GROUPS * m;                 // output index within a branch, 0..H-1
-            float c = wa[5 * H + o];
-#pragma unroll
-            for (int v = 0; v < 5; ++v) c = fmaf(wa[v * H + o], x[v], c);
-            float ob = wa[6 * H + 4 * H + o];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) ob = fmaf(wa[6 * H + v * H + o], x[5 + v], ob);
-            float bs = wa[11 * H + 3 * H + o];
-#pragma unroll
-            for (int v = 0; v < 3; ++v) bs = fmaf(wa[11 * H + v * H + o], x[9 + v], bs);
-            // concat order (PMINet.py:58): comm | obs | boundary_state ; k -> (parity k&1, step k>>1)
-            const int k0 = o, k1 = H + o, k2 = 2 * H + o;
-            h0s[((k0 & 1) * 32 + p) * ROW + (k0 >> 1)] = fmaxf(c, 0.0f);
-            h0s[((k1 & 1) * 32 + p) * ROW + (k1 >> 1)] = fmaxf(ob, 0.0f);
-            h0s[((k2 & 1) * 32 + p) * ROW + (k2 >> 1)] = fmaxf(bs, 0.0f);
+    uint2 pr_cur, pr_next;
+    float4 x_next[3];
+    {
+        float4 x0[3];
+        gather(blockIdx.x, pr_cur, x0);
+        if (tid < 32) {
+            float4 *dst = reinterpret_cast<float4 *>(xs + tid * 12);
+            dst[0] = x0[0]; dst[1] = x0[1]; dst[2] = x0[2];
         }
-        __syncthreads();
-        gather(tile + gridDim.x, pr_next, x_next);          // next tile's loads overlap this tile's MFMAs
+    }
+    gather(blockIdx.x + gridDim.x, pr_next, x_next);
+    __syncthreads();
+
+    int cur = 0;
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // ---- branch layers of this tile, from xs[cur]
+        const float *xt = xs + cur * 32 * 12;
+#pragma unroll 4
+        for (int pp = 0; pp < PPT; ++pp) {
+            const int pr_i = phalf * PPT + pp;
+            const float4 *xp = reinterpret_cast<const float4 *>(xt + pr_i * 12);
+            const float4 xa = xp[0], xb = xp[1], xc = xp[2];
+            float c = bc;
+            c = fmaf(wc[0], xa.x, c); c = fmaf(wc[1], xa.y, c); c = fmaf(wc[2], xa.z, c);
+            c = fmaf(wc[3], xa.w, c); c = fmaf(wc[4], xb.x, c);
+            float ob = bo;
+            ob = fmaf(wo[0], xb.y, ob); ob = fmaf(wo[1], xb.z, ob); ob = fmaf(wo[2], xb.w, ob);
+            ob = fmaf(wo[3], xc.x, ob);
+            float bs = bb;
+            bs = fmaf(wb[0], xc.y, bs); bs = fmaf(wb[1], xc.z, bs); bs = fmaf(wb[2], xc.w, bs);
+            hc0[pr_i * ROW] = fmaxf(c, 0.0f);
+            hc1[pr_i * ROW] = fmaxf(ob, 0.0f);
+            hc2[pr_i * ROW] = fmaxf(bs, 0.0f);
+        }
+        // next tile's inputs go to the other xs buffer; the one after that is fetched under the MFMAs
+        if (tid < 32) {
+            float4 *dst = reinterpret_cast<float4 *>(xs + (cur ^ 1) * 32 * 12 + tid * 12);
+            dst[0] = x_next[0]; dst[1] = x_next[1]; dst[2] = x_next[2];
+        }
+        const uint2 pr_this = pr_cur;
+        pr_cur = pr_next;
+        gather(tile + 2 * gridDim.x, pr_next, x_next);
+        __syncthreads();                                    // activation tile and xs[cur ^ 1] complete
 
         // ---- fc1 (+ folded bn1) on the matrix cores: [32 pairs x 3H] x [3H x 32 cols]
         f32x16 acc;
@@ -157,25 +181,25 @@ __global__ void __launch_bounds__(H * 2) pmi_score_kernel(const PmiParams q)
 
         // ---- ReLU, fc2 (PMINet.py:60-61): per row, sum over this block's 32 columns in a fixed
         //      butterfly order (bitwise reproducible), then over the column blocks in order
+        float *pc = part + cur * NW * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float v = fmaxf(acc[r], 0.0f) * wout;
 #pragma unroll
             for (int msk = 1; msk < 32; msk <<= 1) v += __shfl_xor(v, msk, 64);
             // C/D layout of 32x32 MFMA: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-            if ((lane & 31) == 0) part[w * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh] = v;
+            if ((lane & 31) == 0) pc[w * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh] = v;
         }
-        __syncthreads();
+        __syncthreads();                                    // partials complete; everyone is past the MFMA reads
         if (tid < 32 && tile * 32 + tid < npairs) {
             float sc = b2;
 #pragma unroll
-            for (int ww = 0; ww < NW; ++ww) sc += part[ww * 32 + tid];
-            const unsigned gi = pr.x, bidx = pr.x / q.N, ii = pr.x - bidx * q.N, jj = pr.y;
+            for (int ww = 0; ww < NW; ++ww) sc += pc[ww * 32 + tid];
+            const unsigned gi = pr_this.x, bidx = gi / q.N, ii = gi - bidx * q.N, jj = pr_this.y;
             q.scores[(size_t)gi * q.N + jj] = sc;
             q.scores[((size_t)bidx * q.N + jj) * q.N + ii] = sc;
         }
-        // no third barrier: the next tile writes h0s (everyone is past the MFMA reads) and rewrites
-        // `part` only after its own first barrier, which the readers above reach first
+        cur ^= 1;   // `part` and `xs` are double-buffered by tile parity: two barriers per tile suffice
     }
 }
 
@@ -320,9 +344,10 @@ hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream
     q.scores = env->scores;
     q.pair_total = env->pair_total;
     q.N = env->cfg.n_uav;
-    // persistent workgroups grid-striding over 32-pair tiles: one per CU at H = 128 (288 registers per
-    // lane leave room for one wavefront per SIMD), two at H = 64
-    const int grid = env->pmi.hidden == 128 ? 256 : 512;
+    // persistent workgroups grid-striding over 32-pair tiles, two per CU: __launch_bounds__(2H, 2) holds
+    // the kernel to 256 registers per lane (a few spills at H = 128) so that one workgroup's branch
+    // layers / epilogue overlap the other's MFMAs -- measured +12 % over one 296-register workgroup
+    const int grid = 512;
     if (env->pmi.hidden == 128)
         hipLaunchKernelGGL(pmi_score_kernel<128>, dim3(grid), dim3(256), 0, stream, q);
     else if (env->pmi.hidden == 64)

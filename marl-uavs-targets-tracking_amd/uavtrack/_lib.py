@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libuavtrack.so")
+# UAVTRACK_LIB points at another build of the same ABI (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("UAVTRACK_LIB") or os.path.join(_HERE, "libuavtrack.so")
 
 ABI_VERSION = 1
 OBS_DIM = 12
