@@ -215,6 +215,23 @@ def test_pmi_edge_cases_and_step_many(uavtrack, pmi_state_dict):
         assert torch.equal(rew, many["reward"][t]) and torch.equal(obs, many["obs"][t])
         ep[:, 0] += rew.mean(1); ep[:, 1:4] += b.info["terms"].mean(2).T; ep[:, 4] += b.info["covered"]
     torch.testing.assert_close(many["ep_sums"], ep, rtol=1e-5, atol=1e-5)
+    # a scratch budget of a few MB forces several scoring chunks per call: same bits as one chunk
+    import os
+    os.environ["UAVTRACK_PMI_SCRATCH_MB"] = "1"
+    try:
+        d = uavtrack.BatchedUavEnv(cfg); d.set_pmi(pmi_state_dict); d.reset(seed=9)
+        chunked = d.step_many(act)
+    finally:
+        del os.environ["UAVTRACK_PMI_SCRATCH_MB"]
+    for k in ("obs", "reward", "terms", "covered"):
+        assert torch.equal(chunked[k], many[k]), k
+    torch.testing.assert_close(chunked["ep_sums"], many["ep_sums"], rtol=1e-6, atol=1e-6)
+    # uavtrack_step_accumulate on the MAAC-R path
+    e2 = uavtrack.BatchedUavEnv(cfg); e2.set_pmi(pmi_state_dict); e2.reset(seed=9)
+    acc = torch.zeros(40, 5, device="cuda")
+    for t in range(6):
+        e2.step(act[t], ep_sums=acc)
+    torch.testing.assert_close(acc, ep, rtol=1e-5, atol=1e-5)
     # and a PMI env without weights refuses to step
     c = uavtrack.BatchedUavEnv(cfg); c.reset(seed=1)
     with pytest.raises(RuntimeError, match="set_pmi_weights"):
