@@ -337,9 +337,11 @@ def main():
             torch.manual_seed(args.seed)
             actor = uavtrack.ActorMLP(action_dim=12 * (3 if args.dim == 3 else 1)).to(device)
             cl = {}
-            for mode in ("eager", "graph"):
+            modes = ("eager", "graph") + (("greedy_graph",) if args.dim == 2 else ())
+            for mode in modes:
                 env = make_env(uavtrack, args, B, device)
-                ro = uavtrack.BatchedRollout(env, actor, steps_per_graph=10, use_graph=(mode == "graph"))
+                ro = uavtrack.BatchedRollout(env, "greedy" if mode == "greedy_graph" else actor, steps_per_graph=10,
+                                             use_graph=(mode != "eager"))
                 ro.reset(seed=args.seed)
                 ro.run(40)
                 torch.cuda.synchronize(device)
@@ -350,7 +352,9 @@ def main():
                 cl[mode] = {"agent_steps_per_s": B * N * 400 / dt, "ms_per_step": dt * 1e3 / 400}
                 env.close()
             cl["note"] = ("reference-shaped shared actor (12-256-12 softmax, random init) + categorical sample + "
-                          "uavtrack_step + episode accumulators, all on device; graph = 10 steps per HIP-graph replay")
+                          "uavtrack_step_accumulate, all on device; graph = 10 steps per HIP-graph replay; greedy_graph = the "
+                          "reference's C-METHOD baseline policy (uav.py:324-369) from the library's own kernel instead of "
+                          "the torch actor")
             line["closed_loop"] = cl
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)

@@ -153,6 +153,14 @@ int uavtrack_step_accumulate(uavtrack_env *env, const int32_t *actions,
                              float *obs, float *reward, float *terms,
                              int32_t *covered, uint8_t *done, float *ep_sums, void *stream);
 
+/* Replaces UAV.get_action_by_direction (uav.py:324-369), the C-METHOD greedy baseline policy, for
+ * every UAV on the current state: actions [B][N] int32 out.  score_t = 1/d(u,t) - 0.8 * #{other UAVs
+ * within dc of t}, first best target, angle = atan2 - heading, epsilon 0.25 random action, 0.3
+ * keep-straight.  The reference calls an undefined find_closest_a_idx (uav.py:368); here it is the
+ * turn rate of uav.py:73-81 nearest to the wrapped angle (lowest index on ties).  Draws are Philox
+ * keyed by (seed, env_offset + b, step_count[b], uav).  2-D only. */
+int uavtrack_greedy_actions(uavtrack_env *env, uint64_t seed, int32_t *actions, void *stream);
+
 /* MAAC-R accounting for reports: out[0] = neighbour pairs scored by the PMI network since
  * the weights were set (each unordered pair once per step).  Synchronises `stream`. */
 int uavtrack_pmi_pairs_scored(uavtrack_env *env, uint64_t *out, void *stream);

@@ -409,6 +409,16 @@ int uavtrack_step_many(uavtrack_env *env, int32_t T, const int32_t *actions, flo
     return run_steps(env, T, actions, obs, reward, terms, covered, done, ep_sums, stream, "uavtrack_step_many");
 }
 
+int uavtrack_greedy_actions(uavtrack_env *env, uint64_t seed, int32_t *actions, void *stream)
+{
+    if (!env) return fail("uavtrack_greedy_actions: null handle");
+    if (!actions) return fail("uavtrack_greedy_actions: actions is null");
+    if (env->cfg.dim != 2) return fail("uavtrack_greedy_actions: the reference baseline is planar (dim must be 2)");
+    HIP_TRY(hipSetDevice(env->cfg.device_id));
+    HIP_TRY(launch_greedy(env, seed, actions, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 int uavtrack_pmi_pairs_scored(uavtrack_env *env, uint64_t *out, void *stream)
 {
     if (!env || !out) return fail("uavtrack_pmi_pairs_scored: null argument");

@@ -102,6 +102,9 @@ hipError_t launch_pmi_finalize(const uavtrack_env *env, int steps, float *reward
 hipError_t launch_ep_sums(const uavtrack_env *env, int steps, const float *reward, const float *terms,
                           const int32_t *covered, float *ep_sums, bool add, hipStream_t stream);
 
+// policy_kernel.hip
+hipError_t launch_greedy(const uavtrack_env *env, uint64_t seed, int32_t *actions, hipStream_t stream);
+
 // reset_kernel.hip
 hipError_t launch_reset(const uavtrack_env *env, uint64_t seed, uint32_t episode, float *obs,
                         hipStream_t stream);

@@ -1,0 +1,120 @@
+// policy_kernel.hip -- the C-METHOD greedy baseline policy, UAV.get_action_by_direction
+// (reference src/agent/uav.py:324-369), for every UAV of every environment.
+//
+// Per UAV: score_t = 1 / d(u, t) - 0.8 * #{other UAVs (compared by position, uav.py:351) within dc
+// of t}; the first best target wins; angle = atan2(ty - y, tx - x) - heading; with probability 0.25
+// a uniformly random action instead (uav.py:338-339), with probability 0.3 the angle is zeroed
+// (uav.py:365-366).  The reference then calls an undefined find_closest_a_idx (uav.py:368); it is
+// defined here as the turn rate of uav.py:73-81 nearest to the wrapped angle, lowest index on ties.
+// Random draws: Philox keyed by (seed, global env, step_count, uav).
+//
+// The reference's O(N M N) loop collapses: the number of UAVs within dc of a target is computed once
+// per (env, target) by the target's lane; a UAV subtracts itself and the UAVs that share its exact
+// position when it is itself within dc.  Same geometry as the step kernel (E whole envs per workgroup,
+// one lane per UAV, poses staged in LDS).
+
+#include "internal.h"
+#include "philox.h"
+
+namespace uavtrack {
+
+namespace {
+
+struct GreedyParams {
+    const float *ux, *uy, *uh, *tx, *ty;
+    const int32_t *step_count;
+    int32_t *actions;
+    int32_t B, N, M, E, na;
+    float dc2, turn_unit;
+    int64_t env_offset;
+    uint32_t k0, k1;
+};
+
+__global__ void __launch_bounds__(kMaxWorkgroup) greedy_policy_kernel(const GreedyParams p)
+{
+    extern __shared__ float2 gsm[];
+    const int N = p.N, M = p.M, E = p.E;
+    float2 *upos = gsm;                               // [E][N]
+    float2 *tpos = upos + E * N;                      // [E][M]
+    int *near_cnt = reinterpret_cast<int *>(tpos + E * M);   // [E][M] UAVs within dc of the target
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int env0 = blockIdx.x * E;
+    const int envs_here = min(E, p.B - env0);
+    const int e = tid / N, i = tid - e * N;
+    const bool active = tid < E * N && e < envs_here;
+    const size_t g = (size_t)(env0 + e) * N + i;
+    float x = 0, y = 0, h = 0;
+    if (active) {
+        x = p.ux[g]; y = p.uy[g]; h = p.uh[g];
+        upos[tid] = make_float2(x, y);
+    }
+    for (int q = tid; q < envs_here * M; q += nthreads)
+        tpos[q] = make_float2(p.tx[(size_t)env0 * M + q], p.ty[(size_t)env0 * M + q]);
+    __syncthreads();
+    for (int q = tid; q < envs_here * M; q += nthreads) {
+        const int te = q / M;
+        const float2 t = tpos[q];
+        int c = 0;
+        for (int j = 0; j < N; ++j) {
+            const float2 u = upos[te * N + j];
+            c += (fmaf(u.y - t.y, u.y - t.y, (u.x - t.x) * (u.x - t.x)) < p.dc2) ? 1 : 0;   // strict, uav.py:353
+        }
+        near_cnt[q] = c;
+    }
+    __syncthreads();
+    if (!active) return;
+
+    const uint64_t genv = (uint64_t)(p.env_offset + env0 + e);
+    const Philox4 r = philox4x32_10((uint32_t)genv, (uint32_t)p.step_count[env0 + e], (uint32_t)i,
+                                    0x47524459u ^ (uint32_t)(genv >> 32), p.k0, p.k1);
+    if (u01(r.v[0]) < 0.25f) {                                         // uav.py:338-339
+        p.actions[g] = (int32_t)(((uint64_t)r.v[1] * (uint32_t)p.na) >> 32);
+        return;
+    }
+    int same = 0;                                                      // UAVs at my exact position (me included)
+    for (int j = 0; j < N; ++j) {
+        const float2 u = upos[e * N + j];
+        same += (u.x == x && u.y == y) ? 1 : 0;
+    }
+    float best = -INFINITY, best_dx = 1.0f, best_dy = 0.0f;
+    for (int k = 0; k < M; ++k) {                                      // uav.py:341-362
+        const float2 t = tpos[e * M + k];
+        const float dx = t.x - x, dy = t.y - y;
+        const float d2 = fmaf(dy, dy, dx * dx);
+        const int others = near_cnt[e * M + k] - (d2 < p.dc2 ? same : 0);
+        const float score = 1.0f / sqrtf(d2) - 0.8f * (float)others;
+        if (score > best) { best = score; best_dx = dx; best_dy = dy; }
+    }
+    float angle = atan2f(best_dy, best_dx) - h;
+    if (M == 0 || u01(r.v[2]) < 0.3f) angle = 0.0f;                    // uav.py:365-366
+    // wrap to [-pi, pi), then the nearest of the na turn rates (2a + 1 - na) * turn_unit
+    angle -= kTwoPi * floorf((angle + kPi) * (1.0f / kTwoPi));
+    int besta = 0;
+    float bestd = INFINITY;
+    for (int a = 0; a < p.na; ++a) {
+        const float dd = fabsf(angle - (float)(2 * a + 1 - p.na) * p.turn_unit);
+        if (dd < bestd) { bestd = dd; besta = a; }
+    }
+    p.actions[g] = besta;
+}
+
+}  // namespace
+
+hipError_t launch_greedy(const uavtrack_env *env, uint64_t seed, int32_t *actions, hipStream_t stream)
+{
+    const uavtrack_config &c = env->cfg;
+    GreedyParams p;
+    p.ux = env->state.ux; p.uy = env->state.uy; p.uh = env->state.uh;
+    p.tx = env->state.tx; p.ty = env->state.ty;
+    p.step_count = env->state.step_count;
+    p.actions = actions;
+    p.B = c.n_envs; p.N = c.n_uav; p.M = c.m_targets; p.E = env->geo.envs_per_wg; p.na = c.na;
+    p.dc2 = env->base.dc2; p.turn_unit = env->base.turn_unit;
+    p.env_offset = c.env_offset;
+    p.k0 = (uint32_t)seed; p.k1 = (uint32_t)(seed >> 32);
+    const size_t lds = (size_t)p.E * (p.N * 8 + p.M * 8 + p.M * 4);
+    hipLaunchKernelGGL(greedy_policy_kernel, dim3(env->geo.groups), dim3(env->geo.wgs), lds, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace uavtrack

@@ -183,6 +183,13 @@ class BatchedUavEnv:
         _lib.check(self._lib.uavtrack_set_pmi_weights(self._h, C.c_void_p(blob.ctypes.data), blob.size, hidden,
                                                       self._stream()), "uavtrack_set_pmi_weights")
 
+    def greedy_actions(self, seed: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The reference's C-METHOD baseline policy (uav.py:324-369) for every UAV -> int32 [B, N]."""
+        a = out if out is not None else self._empty((self.B, self.N), torch.int32)
+        _lib.check(self._lib.uavtrack_greedy_actions(self._h, C.c_uint64(seed & (2 ** 64 - 1)), _ptr(a),
+                                                     self._stream()), "uavtrack_greedy_actions")
+        return a
+
     def pmi_pairs_scored(self) -> int:
         """Neighbour pairs the PMI network has scored so far (synchronises the stream)."""
         out = C.c_uint64(0)

@@ -38,10 +38,12 @@ def sample_actions(probs: torch.Tensor) -> torch.Tensor:
 
 
 class BatchedRollout:
-    def __init__(self, env: BatchedUavEnv, policy: Callable[[torch.Tensor], torch.Tensor],
-                 select: Callable[[torch.Tensor], torch.Tensor] = sample_actions,
-                 steps_per_graph: int = 8, use_graph: bool = True):
-        self.env, self.policy, self.select = env, policy, select
+    """policy = callable obs[B,N,12] -> probs[B,N,na] (e.g. ActorMLP), or the string "greedy" for the
+    reference's C-METHOD baseline (uav.py:324-369) computed by the library's own policy kernel."""
+
+    def __init__(self, env: BatchedUavEnv, policy, select: Callable[[torch.Tensor], torch.Tensor] = sample_actions,
+                 steps_per_graph: int = 8, use_graph: bool = True, seed: int = 0):
+        self.env, self.policy, self.select, self.seed = env, policy, select, seed
         self.k = max(1, int(steps_per_graph))
         self.use_graph = use_graph
         B = env.B
@@ -53,8 +55,12 @@ class BatchedRollout:
 
     # one closed-loop step on the current stream; everything stays on the device
     def _one_step(self):
-        with torch.no_grad():
-            actions = self.select(self.policy(self.obs))
+        if isinstance(self.policy, str):
+            assert self.policy == "greedy", self.policy
+            actions = self.env.greedy_actions(self.seed)     # draws are keyed by (seed, env, step_count, uav)
+        else:
+            with torch.no_grad():
+                actions = self.select(self.policy(self.obs))
         obs, reward, _ = self.env.step(actions, ep_sums=self.ep)   # the kernel adds to the accumulators
         self.obs.copy_(obs)
         self.last_reward.copy_(reward)

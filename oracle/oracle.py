@@ -69,6 +69,7 @@ def lib():
         _lib.orc_reset_obs.restype = C.c_int
         _lib.orc_reset_philox.restype = C.c_int
         _lib.orc_philox4x32_10.restype = None
+        _lib.orc_greedy_actions.restype = C.c_int
     return _lib
 
 
@@ -219,6 +220,22 @@ class OracleEnv:
         if rc != 0:
             raise RuntimeError(f"orc_step failed: {rc}")
         return dict(obs=obs, reward=reward, terms=terms, raw=raw, covered=covered, margin=margin)
+
+
+def greedy_actions(env: "OracleEnv", seed: int, step_count, env_offset: int = 0):
+    """uav.py:324-369 on the oracle env's current state -> (actions[B,N], margins dict)."""
+    cfg = env.cfg
+    B, N = cfg.n_envs, cfg.n_uav
+    sc = np.ascontiguousarray(np.asarray(step_count, dtype=np.int32).reshape(B))
+    act = np.empty((B, N), dtype=np.int32)
+    ms, ma, md = np.empty(B), np.empty(B), np.empty(B)
+    c = cfg.c_struct()
+    rc = lib().orc_greedy_actions(C.byref(c), C.c_uint64(seed), C.c_int64(env_offset), _ip(sc),
+                                  _dp(env.ux), _dp(env.uy), _dp(env.uh), _dp(env.tx), _dp(env.ty),
+                                  _ip(act), _dp(ms), _dp(ma), _dp(md))
+    if rc != 0:
+        raise RuntimeError(f"orc_greedy_actions failed: {rc}")
+    return act, dict(score=ms, angle=ma, dist=md)
 
 
 def philox4x32_10(ctr, key):

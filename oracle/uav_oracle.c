@@ -481,3 +481,72 @@ int orc_reset_philox(const orc_config *cfg, uint64_t seed, uint32_t episode,
     }
     return 0;
 }
+
+/* ---- greedy baseline policy, uav.py:324-369 -------------------------------------------------- */
+int orc_greedy_actions(const orc_config *cfg, uint64_t seed, int64_t env_offset, const int32_t *step_count,
+                       const double *ux, const double *uy, const double *uh,
+                       const double *tx, const double *ty,
+                       int32_t *actions, double *mg_score, double *mg_angle, double *mg_dist)
+{
+    const int B = cfg->n_envs, N = cfg->n_uav, M = cfg->m_targets, na = cfg->na;
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    long b;
+    if (cfg->dim != 2) return -1;
+    for (b = 0; b < B; ++b) {
+        const double *x = ux + (size_t)b * N, *y = uy + (size_t)b * N, *h = uh + (size_t)b * N;
+        const double *gx = tx + (size_t)b * M, *gy = ty + (size_t)b * M;
+        const uint64_t gid = (uint64_t)(env_offset + b);
+        double ms = INFINITY, ma = INFINITY, md = INFINITY;
+        int i, j, k, a;
+        for (i = 0; i < N; ++i) {
+            uint32_t ctr[4] = {(uint32_t)gid, (uint32_t)step_count[b], (uint32_t)i, 0x47524459u ^ (uint32_t)(gid >> 32)};
+            uint32_t r[4];
+            double best = -INFINITY, second = -INFINITY, best_angle = 0.0;
+            orc_philox4x32_10(ctr, key, r);
+            if (u01f(r[0]) < 0.25f) {                               /* uav.py:338-339 */
+                actions[(size_t)b * N + i] = (int32_t)(((uint64_t)r[1] * (uint32_t)na) >> 32);
+                continue;
+            }
+            for (k = 0; k < M; ++k) {                               /* uav.py:341-362 */
+                const double d_t = dist2(x[i], y[i], gx[k], gy[k]);
+                double pen = 0.0, score;
+                for (j = 0; j < N; ++j) {
+                    if (x[j] != x[i] || y[j] != y[i]) {             /* `(uav_x, uav_y) != (self.x, self.y)` */
+                        const double d = dist2(x[j], y[j], gx[k], gy[k]);
+                        note_margin(&md, d, cfg->dc);
+                        if (d < cfg->dc) pen += 0.8;
+                    }
+                }
+                score = 1.0 / d_t - pen;
+                if (score > best) {
+                    second = best;
+                    best = score;
+                    best_angle = atan2(gy[k] - y[i], gx[k] - x[i]) - h[i];
+                } else if (score > second) {
+                    second = score;
+                }
+            }
+            if (best - second < ms) ms = best - second;
+            const int straight = u01f(r[2]) < 0.3f;                 /* uav.py:365-366 */
+            if (straight) best_angle = 0.0;
+            {   /* find_closest_a_idx, defined here: nearest turn rate of uav.py:73-81 to the wrapped angle */
+                const double ang = py_fmod_pos(best_angle + ORC_PI, 2.0 * ORC_PI) - ORC_PI;
+                double bestd = INFINITY, secondd = INFINITY;
+                int besta = 0;
+                for (a = 0; a < na; ++a) {
+                    const double w = cfg->dt * (2.0 * (a + 1) - na - 1) * cfg->u_h_max / (na - 1);
+                    const double dd = fabs(ang - w);
+                    if (dd < bestd) { secondd = bestd; bestd = dd; besta = a; }
+                    else if (dd < secondd) secondd = dd;
+                }
+                /* angle 0 sits exactly between the two middle turn rates: an exact tie, lowest index wins */
+                if (!straight && (secondd - bestd) * 0.5 < ma) ma = (secondd - bestd) * 0.5;
+                actions[(size_t)b * N + i] = besta;
+            }
+        }
+        if (mg_score) mg_score[b] = ms;
+        if (mg_angle) mg_angle[b] = ma;
+        if (mg_dist) mg_dist[b] = md;
+    }
+    return 0;
+}

@@ -134,3 +134,23 @@ def test_threads_agree():
     oa, ob = a.step(act), b.step(act)
     for k in oa:
         np.testing.assert_array_equal(oa[k], ob[k])
+
+
+def test_greedy_policy_restatement_semantics():
+    """uav.py:324-369 restated: nearest target wins when nobody else is near it; a target crowded by
+    other UAVs (within dc) loses 0.8 per UAV; keep-straight maps to the lower of the two middle actions."""
+    from oracle import greedy_actions
+    cfg = OracleConfig(n_envs=1, n_uav=3, m_targets=2)
+    env = OracleEnv(cfg)
+    # UAV 0 at the origin-ish heading east; target 0 due north 300 m (crowded by UAVs 1, 2), target 1 due east 900 m (free)
+    env.set_state(ux=[100.0, 100.0, 120.0], uy=[100.0, 380.0, 420.0], uh=[0.0, 0.0, 0.0], ua=[0, 0, 0],
+                  tx=[100.0, 1000.0], ty=[400.0, 100.0], th=[0.0, 0.0])
+    seen = set()
+    for seed in range(40):
+        a, _ = greedy_actions(env, seed, np.zeros(1, np.int32))
+        seen.add(int(a[0, 0]))
+    # besides random draws, UAV 0 either keeps straight (5) or steers to the FREE target, which is dead
+    # ahead (angle 0 -> 5 as well): never the hard-left 11 a nearest-target rule would pick
+    assert 5 in seen
+    counts = [sum(int(greedy_actions(env, s, np.zeros(1, np.int32))[0][0, 0]) == v for s in range(200)) for v in (5, 11)]
+    assert counts[0] > 120 and counts[1] < 30
