@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Long teacher-forced comparison HIP vs oracle (GPU box; not part of the test suite): many envs,
+many steps, several boxes, so that rare paths (wall mirrors, heading wraps, near-origin weights,
+UAVs outside the box, crowded neighbourhoods) all occur."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "marl-uavs-targets-tracking_amd")]
+import torch
+import uavtrack
+from oracle import OracleConfig, OracleEnv
+
+def run(B, N, M, coop, box, steps, seed, dim=2):
+    kw = dict(n_envs=B, n_uav=N, m_targets=M, cooperative=coop, x_max=box, y_max=box, dim=dim, nc=3 if dim == 3 else 1, z_max=300.0)
+    env = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(**kw)); env.reset(seed=seed)
+    orc = OracleEnv(OracleConfig(**kw), n_threads=16)
+    rng = np.random.RandomState(seed)
+    worst = dict(obs=0.0, rew=0.0, terms=0.0); bad_cov = 0; skipped = 0; total = 0
+    na = 12 * (3 if dim == 3 else 1)
+    for t in range(steps):
+        st = {k: v.cpu().numpy() for k, v in env.get_state().items()}
+        orc.set_state(st["ux"], st["uy"], st["uh"], st["ua"], st["tx"], st["ty"], st["th"], uz=st.get("uz"), tz=st.get("tz"))
+        act = rng.randint(0, na, size=(B, N)).astype(np.int32)
+        obs, rew, _ = env.step(torch.from_numpy(act))
+        ref = orc.step(act)
+        ok = ref["margin"] > 1e-3
+        skipped += int((~ok).sum()); total += B
+        o = obs.cpu().numpy(); r = rew.cpu().numpy(); tm = env.info["terms"].cpu().numpy(); cv = env.info["covered"].cpu().numpy()
+        # near the origin the uav.py:165 weight 1/min(d,1) makes observation entries O(10..1000): mixed abs/rel
+        worst["obs"] = max(worst["obs"], float((np.abs(o - ref["obs"]) / (1.0 + np.abs(ref["obs"])))[ok].max()))
+        worst["rew"] = max(worst["rew"], float(np.abs(r - ref["reward"])[ok].max()))
+        worst["terms"] = max(worst["terms"], float(np.abs(tm - ref["terms"])[:, ok].max()))
+        bad_cov += int((cv != ref["covered"])[ok].sum())
+    print(f"B{B} N{N} M{M} coop{coop} box{box} dim{dim} steps{steps}: max|obs|={worst['obs']:.2e} max|rew|={worst['rew']:.2e} "
+          f"max|terms|={worst['terms']:.2e} covered mismatches={bad_cov} knife-edge envs skipped={skipped}/{total}", flush=True)
+    assert worst["obs"] < 1e-5 and worst["rew"] < 1e-5 and worst["terms"] < 1e-5 and bad_cov == 0
+
+t0 = time.time()
+if "--quick" not in sys.argv:
+    run(4096, 20, 10, 0.0, 2000.0, 200, 1)
+    run(4096, 20, 10, 0.3, 2000.0, 100, 2)
+run(2048, 20, 10, 0.3, 300.0, 150, 3)     # tiny box: everything in range, UAVs leave the box, many reflections
+run(1024, 50, 25, 0.3, 2000.0, 60, 4)
+run(1024, 50, 25, 0.0, 2000.0, 40, 5, dim=3)
+run(2048, 7, 4, 0.3, 100.0, 300, 6)       # generic kernel, box smaller than a step: origin-weight path, outside-box UAVs
+print(f"soak ok in {time.time()-t0:.0f} s")
