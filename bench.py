@@ -351,10 +351,23 @@ def main():
                 dt = time.perf_counter() - t0
                 cl[mode] = {"agent_steps_per_s": B * N * 400 / dt, "ms_per_step": dt * 1e3 / 400}
                 env.close()
+            if args.dim == 2:      # the same closed loop fused into one launch per 200-step episode
+                env = make_env(uavtrack, args, B, device)
+                env.reset(seed=args.seed)
+                env.run_greedy(200, seed=args.seed)
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    env.reset(seed=args.seed)
+                    env.run_greedy(200, seed=args.seed)
+                torch.cuda.synchronize(device)
+                dt = time.perf_counter() - t0
+                cl["greedy_fused"] = {"agent_steps_per_s": B * N * 1000 / dt, "ms_per_step": dt * 1e3 / 1000}
+                env.close()
             cl["note"] = ("reference-shaped shared actor (12-256-12 softmax, random init) + categorical sample + "
                           "uavtrack_step_accumulate, all on device; graph = 10 steps per HIP-graph replay; greedy_graph = the "
                           "reference's C-METHOD baseline policy (uav.py:324-369) from the library's own kernel instead of "
-                          "the torch actor")
+                          "the torch actor; greedy_fused = uavtrack_run_greedy, policy and step of a whole 200-step episode in one launch")
             line["closed_loop"] = cl
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)

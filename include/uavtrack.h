@@ -161,6 +161,15 @@ int uavtrack_step_accumulate(uavtrack_env *env, const int32_t *actions,
  * keyed by (seed, env_offset + b, step_count[b], uav).  2-D only. */
 int uavtrack_greedy_actions(uavtrack_env *env, uint64_t seed, int32_t *actions, void *stream);
 
+/* The whole C-METHOD evaluation loop of train.run_epoch (train.py:326-370) in ONE launch: per step the
+ * baseline policy above picks the actions from the current state, then Environment.step runs -- T
+ * closed-loop steps with the state on chip.  Bitwise identical to T x (uavtrack_greedy_actions,
+ * uavtrack_step).  actions_out (nullable) [T][B][N] receives the chosen actions; the other outputs are
+ * those of uavtrack_step_many.  Reward modes RAW / MEAN, 2-D only. */
+int uavtrack_run_greedy(uavtrack_env *env, int32_t T, uint64_t seed, int32_t *actions_out,
+                        float *obs, float *reward, float *terms,
+                        int32_t *covered, uint8_t *done, float *ep_sums, void *stream);
+
 /* MAAC-R accounting for reports: out[0] = neighbour pairs scored by the PMI network since
  * the weights were set (each unordered pair once per step).  Synchronises `stream`. */
 int uavtrack_pmi_pairs_scored(uavtrack_env *env, uint64_t *out, void *stream);

@@ -349,6 +349,7 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
     p.covered = covered; p.done = done; p.ep_sums = ep_sums;
     p.pairs = nullptr; p.pair_count = nullptr;
     p.ep_accumulate = accumulate ? 1 : 0;
+    p.actions_out = nullptr;
     if (env->cfg.reward_mode != UAVTRACK_REWARD_PMI) {
         p.T = T;
         HIP_TRY(launch_rollout(env, p, st));
@@ -407,6 +408,28 @@ int uavtrack_step_many(uavtrack_env *env, int32_t T, const int32_t *actions, flo
                        float *terms, int32_t *covered, uint8_t *done, float *ep_sums, void *stream)
 {
     return run_steps(env, T, actions, obs, reward, terms, covered, done, ep_sums, stream, "uavtrack_step_many");
+}
+
+int uavtrack_run_greedy(uavtrack_env *env, int32_t T, uint64_t seed, int32_t *actions_out, float *obs, float *reward,
+                        float *terms, int32_t *covered, uint8_t *done, float *ep_sums, void *stream)
+{
+    if (!env) return fail("uavtrack_run_greedy: null handle");
+    if (T < 1) return fail("uavtrack_run_greedy: T must be >= 1 (got %d)", T);
+    if (!reward) return fail("uavtrack_run_greedy: reward is null");
+    if (env->cfg.dim != 2) return fail("uavtrack_run_greedy: the reference baseline is planar (dim must be 2)");
+    if (env->cfg.reward_mode == UAVTRACK_REWARD_PMI)
+        return fail("uavtrack_run_greedy: the C-METHOD baseline runs with the MAAC / MAAC-G rewards (C-METHOD.yaml: cooperative 0)");
+    HIP_TRY(hipSetDevice(env->cfg.device_id));
+    StepParams p = env->base;
+    p.T = T;
+    p.actions = nullptr; p.actions_out = actions_out;
+    p.obs = obs; p.reward = reward; p.terms = terms; p.pose_out = nullptr;
+    p.covered = covered; p.done = done; p.ep_sums = ep_sums;
+    p.pairs = nullptr; p.pair_count = nullptr; p.ep_accumulate = 0;
+    p.env_offset = env->cfg.env_offset;
+    p.greedy_k0 = (uint32_t)seed; p.greedy_k1 = (uint32_t)(seed >> 32);
+    HIP_TRY(launch_rollout(env, p, static_cast<hipStream_t>(stream), true));
+    return 0;
 }
 
 int uavtrack_greedy_actions(uavtrack_env *env, uint64_t seed, int32_t *actions, void *stream)

@@ -40,6 +40,10 @@ struct StepParams {
     // geometry
     int32_t B, N, M, E, T, na, na_total, horizon;
     int32_t ep_accumulate;   // 1: ep_sums += (uavtrack_step_accumulate), 0: ep_sums = sums of this launch
+    // fused greedy rollout (uavtrack_run_greedy): actions come from the in-kernel baseline policy
+    int32_t *actions_out;    // [T][B][N], nullable
+    int64_t env_offset;
+    uint32_t greedy_k0, greedy_k1;
     // constants
     float x_max, y_max, z_max;
     float dtv_u, dtv_t;          // dt * v_max of UAVs / targets
@@ -92,7 +96,7 @@ namespace uavtrack {
 
 // step_kernel.hip
 Geometry plan_geometry(const uavtrack_config &cfg);
-hipError_t launch_rollout(const uavtrack_env *env, const StepParams &p, hipStream_t stream);
+hipError_t launch_rollout(const uavtrack_env *env, const StepParams &p, hipStream_t stream, bool greedy = false);
 
 // pmi_kernel.hip
 bool pmi_hidden_supported(int hidden);

@@ -13,8 +13,7 @@
 // position when it is itself within dc.  Same geometry as the step kernel (E whole envs per workgroup,
 // one lane per UAV, poses staged in LDS).
 
-#include "internal.h"
-#include "philox.h"
+#include "greedy.h"
 
 namespace uavtrack {
 
@@ -53,49 +52,15 @@ __global__ void __launch_bounds__(kMaxWorkgroup) greedy_policy_kernel(const Gree
     __syncthreads();
     for (int q = tid; q < envs_here * M; q += nthreads) {
         const int te = q / M;
-        const float2 t = tpos[q];
-        int c = 0;
-        for (int j = 0; j < N; ++j) {
-            const float2 u = upos[te * N + j];
-            c += (fmaf(u.y - t.y, u.y - t.y, (u.x - t.x) * (u.x - t.x)) < p.dc2) ? 1 : 0;   // strict, uav.py:353
-        }
-        near_cnt[q] = c;
+        near_cnt[q] = greedy_near_count(tpos[q], N, p.dc2, [&](int j) { return upos[te * N + j]; });
     }
     __syncthreads();
     if (!active) return;
-
-    const uint64_t genv = (uint64_t)(p.env_offset + env0 + e);
-    const Philox4 r = philox4x32_10((uint32_t)genv, (uint32_t)p.step_count[env0 + e], (uint32_t)i,
-                                    0x47524459u ^ (uint32_t)(genv >> 32), p.k0, p.k1);
-    if (u01(r.v[0]) < 0.25f) {                                         // uav.py:338-339
-        p.actions[g] = (int32_t)(((uint64_t)r.v[1] * (uint32_t)p.na) >> 32);
-        return;
-    }
-    int same = 0;                                                      // UAVs at my exact position (me included)
-    for (int j = 0; j < N; ++j) {
-        const float2 u = upos[e * N + j];
-        same += (u.x == x && u.y == y) ? 1 : 0;
-    }
-    float best = -INFINITY, best_dx = 1.0f, best_dy = 0.0f;
-    for (int k = 0; k < M; ++k) {                                      // uav.py:341-362
-        const float2 t = tpos[e * M + k];
-        const float dx = t.x - x, dy = t.y - y;
-        const float d2 = fmaf(dy, dy, dx * dx);
-        const int others = near_cnt[e * M + k] - (d2 < p.dc2 ? same : 0);
-        const float score = 1.0f / sqrtf(d2) - 0.8f * (float)others;
-        if (score > best) { best = score; best_dx = dx; best_dy = dy; }
-    }
-    float angle = atan2f(best_dy, best_dx) - h;
-    if (M == 0 || u01(r.v[2]) < 0.3f) angle = 0.0f;                    // uav.py:365-366
-    // wrap to [-pi, pi), then the nearest of the na turn rates (2a + 1 - na) * turn_unit
-    angle -= kTwoPi * floorf((angle + kPi) * (1.0f / kTwoPi));
-    int besta = 0;
-    float bestd = INFINITY;
-    for (int a = 0; a < p.na; ++a) {
-        const float dd = fabsf(angle - (float)(2 * a + 1 - p.na) * p.turn_unit);
-        if (dd < bestd) { bestd = dd; besta = a; }
-    }
-    p.actions[g] = besta;
+    p.actions[g] = greedy_pick(x, y, h, i, N, M, p.na, p.dc2, p.turn_unit, (uint64_t)(p.env_offset + env0 + e),
+                               (uint32_t)p.step_count[env0 + e], p.k0, p.k1,
+                               [&](int j) { return upos[e * N + j]; },
+                               [&](int k) { return tpos[e * M + k]; },
+                               [&](int k) { return near_cnt[e * M + k]; });
 }
 
 }  // namespace

@@ -34,7 +34,7 @@
 //
 // No MFMA: there is no dense contraction on this path.
 
-#include "internal.h"
+#include "greedy.h"
 
 #include <cstdlib>
 
@@ -315,7 +315,7 @@ __device__ __forceinline__ void sweep_weighted(const StepParams &p, int N, int M
     }
 }
 
-template <int N_, int M_, int MODE, bool Z3>
+template <int N_, int M_, int MODE, bool Z3, bool GREEDY>
 __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams p)
 {
     extern __shared__ float4 smem4[];
@@ -336,6 +336,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     float *thd = fb;   fb += E * M;              // [E][M]      target heading
     float *rawl = fb;  fb += E * (N + 1);        // [E][N + 1]  raw reward (cooperative modes), pair-padded
     float *tzf = fb;   if (Z3) fb += E * MP * 2; // [E][pairs] (z0, z1)
+    int *ncnt = reinterpret_cast<int *>(fb);  fb += E * M;   // [E][M] UAVs within dc of a target (greedy policy)
     unsigned *covw = reinterpret_cast<unsigned *>(fb);   // [2][E * CW] (+ 2 words, MAAC-R pair emission)
 
     const int grp = xcd_group(blockIdx.x, gridDim.x);
@@ -391,7 +392,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         if (Z3) tzf[te * MP * 2 + k] = S.tz[gt];
     }
     int act = 0;
-    if (active) act = p.actions[g];
+    if (!GREEDY && active) act = p.actions[g];
     // Per-lane constants of the step loop: this lane's own slots in both table copies, and (when the
     // workgroup has at least one lane per target, as in every benchmark shape) its target's slot.
     float *const own0 = reinterpret_cast<float *>(uenv + (i >> 1) * 6) + (i & 1);
@@ -407,6 +408,37 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     for (int t = 0; t < p.T; ++t) {
         const size_t tg_off = (size_t)t * BN + g;          // [t][b][i]
         const int cbuf = (t & 1) * E * CW;
+
+        // ---- P0 (fused greedy rollout only): the C-METHOD baseline policy (uav.py:324-369) on the state as it
+        //      stands before this step -- UAV poses are the previous step's post-move copy, targets not yet moved
+        if (GREEDY) {
+            const int pc = pn ^ 1;
+            auto upos_of = [&](const float4 *rows, int j) {
+                const float *f = reinterpret_cast<const float *>(rows + (j >> 1) * 6);
+                return make_float2(f[j & 1], f[2 + (j & 1)]);
+            };
+            auto tpos_of = [&](const float4 *rows, int k) {
+                const float *f = reinterpret_cast<const float *>(rows + (k >> 1) * 2);
+                return make_float2(f[k & 1], f[2 + (k & 1)]);
+            };
+            for (int q = tid; q < envs_here * M; q += nthreads) {
+                const int te = q / M, k = q - te * M;
+                const float4 *rows = utab + te * ustride + pc * 3;
+                ncnt[q] = greedy_near_count(tpos_of(ttab + te * tstride, k), N, p.dc2,
+                                            [&](int j) { return upos_of(rows, j); });
+            }
+            __syncthreads();
+            if (active) {
+                const float4 *rows = uenv + pc * 3;
+                act = greedy_pick(x, y, h, i, N, M, p.na, p.dc2, p.turn_unit, (uint64_t)(p.env_offset + b),
+                                  (uint32_t)count, p.greedy_k0, p.greedy_k1,
+                                  [&](int j) { return upos_of(rows, j); },
+                                  [&](int k) { return tpos_of(tenv, k); },
+                                  [&](int k) { return ncnt[e * M + k]; });
+                if (p.actions_out) p.actions_out[tg_off] = act;
+            }
+            __syncthreads();   // the policy has read the target table; now it may move
+        }
 
         // ---- P1a: targets (target.py:27-60); straight flight, mirror at the walls
         auto advance_target = [&](float *f, int q) {      // f -> x slot of the target; y, cos, sin at +2, +4, +6
@@ -462,9 +494,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                 float *f = own0 + pn * 12;                   // copy pn of this lane's pair row
                 f[0] = x; f[2] = y; f[4] = c; f[6] = s; f[8] = ai; f[10] = z;
             }
-#ifndef UAVTRACK_EXPERIMENT_NO_ACTION_LOADS
-            if (t + 1 < p.T) act = p.actions[tg_off + BN];   // prefetch next step's action
-#endif
+            if (!GREEDY && t + 1 < p.T) act = p.actions[tg_off + BN];   // prefetch next step's action
             if (i == 0)
                 for (int w = 0; w < CW; ++w) covw[cbuf + e * CW + w] = 0;
         }
@@ -676,38 +706,42 @@ size_t lds_bytes_for(int E, int N, int M, bool z3)
 {
     const size_t CW = (M + 31) / 32, MP = pairs_of(M);
     const size_t f4 = (size_t)E * ustride_of(N) + (size_t)E * tstride_of(M);
-    const size_t f = (size_t)E * M + (size_t)E * (N + 1) + (z3 ? (size_t)E * MP * 2 : 0) + 2 * E * CW + 2;
+    const size_t f = (size_t)E * M + (size_t)E * (N + 1) + (z3 ? (size_t)E * MP * 2 : 0) + (size_t)E * M + 2 * E * CW + 2;
     return (f4 * 16 + f * 4 + 15) & ~(size_t)15;   // ustride >= 3 N float4 per env, so ep_sums staging (E N float4) fits
 }
 
 using KernelFn = void (*)(const StepParams);
 
 template <int N_, int M_>
-KernelFn pick_mode(int mode, bool z3)
+KernelFn pick_mode(int mode, bool z3, bool greedy)
 {
+    if (greedy) {   // planar baseline policy; MAAC / MAAC-G rewards
+        return mode == UAVTRACK_REWARD_MEAN ? rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, false, true>
+                                            : rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, false, true>;
+    }
     if (z3) {
         switch (mode) {
-        case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, true>;
-        case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, UAVTRACK_REWARD_PMI, true>;
-        default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, true>;
+        case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, true, false>;
+        case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, UAVTRACK_REWARD_PMI, true, false>;
+        default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, true, false>;
         }
     }
     switch (mode) {
-    case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, false>;
-    case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, UAVTRACK_REWARD_PMI, false>;
-    default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, false>;
+    case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, false, false>;
+    case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, UAVTRACK_REWARD_PMI, false, false>;
+    default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, false, false>;
     }
 }
 
-KernelFn pick_kernel(int N, int M, int mode, bool z3, int *specialised)
+KernelFn pick_kernel(int N, int M, int mode, bool z3, int *specialised, bool greedy = false)
 {
     *specialised = 1;
-    if (N == 20 && M == 10) return pick_mode<20, 10>(mode, z3);
-    if (N == 50 && M == 25) return pick_mode<50, 25>(mode, z3);
-    if (N == 10 && M == 10) return pick_mode<10, 10>(mode, z3);
-    if (N == 5 && M == 3) return pick_mode<5, 3>(mode, z3);
+    if (N == 20 && M == 10) return pick_mode<20, 10>(mode, z3, greedy);
+    if (N == 50 && M == 25) return pick_mode<50, 25>(mode, z3, greedy);
+    if (N == 10 && M == 10) return pick_mode<10, 10>(mode, z3, greedy);
+    if (N == 5 && M == 3) return pick_mode<5, 3>(mode, z3, greedy);
     *specialised = 0;
-    return pick_mode<0, 0>(mode, z3);
+    return pick_mode<0, 0>(mode, z3, greedy);
 }
 
 }  // namespace
@@ -750,10 +784,10 @@ Geometry plan_geometry(const uavtrack_config &cfg)
     return g;
 }
 
-hipError_t launch_rollout(const uavtrack_env *env, const StepParams &p, hipStream_t stream)
+hipError_t launch_rollout(const uavtrack_env *env, const StepParams &p, hipStream_t stream, bool greedy)
 {
     int spec = 0;
-    KernelFn fn = pick_kernel(p.N, p.M, env->cfg.reward_mode, env->cfg.dim == 3, &spec);
+    KernelFn fn = pick_kernel(p.N, p.M, env->cfg.reward_mode, env->cfg.dim == 3, &spec, greedy);
     const Geometry &g = env->geo;
     hipLaunchKernelGGL(fn, dim3(g.groups), dim3(g.wgs), g.lds_bytes, stream, p);
     return hipGetLastError();

@@ -48,6 +48,7 @@ SIGNATURES = {
     "uavtrack_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.c_void_p]),
     "uavtrack_step_accumulate": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.c_void_p]),
     "uavtrack_step_many": (C.c_int, [C.c_void_p, C.c_int32] + [C.c_void_p] * 7 + [C.c_void_p]),
+    "uavtrack_run_greedy": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64] + [C.c_void_p] * 7 + [C.c_void_p]),
     "uavtrack_greedy_actions": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "uavtrack_pmi_pairs_scored": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),
     "uavtrack_kernel_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),

@@ -190,6 +190,23 @@ class BatchedUavEnv:
                                                      self._stream()), "uavtrack_greedy_actions")
         return a
 
+    def run_greedy(self, T: int, seed: int = 0, want_obs: bool = True, want_terms: bool = True,
+                   want_actions: bool = True) -> Dict[str, torch.Tensor]:
+        """T closed-loop steps of the C-METHOD baseline (train.py:326-370) in one launch."""
+        def buf(shape, dtype, want=True):
+            return self._empty(shape, dtype) if want else None
+        acts = buf((T, self.B, self.N), torch.int32, want_actions)
+        obs = buf((T, self.B, self.N, _lib.OBS_DIM), torch.float32, want_obs)
+        reward = buf((T, self.B, self.N), torch.float32)
+        terms = buf((T, 3, self.B, self.N), torch.float32, want_terms)
+        covered = buf((T, self.B), torch.int32)
+        done = buf((T, self.B), torch.uint8)
+        ep = buf((self.B, 5), torch.float32)
+        _lib.check(self._lib.uavtrack_run_greedy(self._h, C.c_int32(T), C.c_uint64(seed & (2 ** 64 - 1)), _ptr(acts),
+                                                 _ptr(obs), _ptr(reward), _ptr(terms), _ptr(covered), _ptr(done),
+                                                 _ptr(ep), self._stream()), "uavtrack_run_greedy")
+        return dict(actions=acts, obs=obs, reward=reward, terms=terms, covered=covered, done=done, ep_sums=ep)
+
     def pmi_pairs_scored(self) -> int:
         """Neighbour pairs the PMI network has scored so far (synchronises the stream)."""
         out = C.c_uint64(0)

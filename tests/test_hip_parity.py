@@ -499,6 +499,22 @@ def test_greedy_baseline_policy_vs_oracle(uavtrack):
         got = env.greedy_actions(seed=seed).cpu().numpy()
         want, _ = greedy_actions(orc, seed, np.zeros(1, np.int32))
         np.testing.assert_array_equal(got, want)
+    # the whole C-METHOD loop fused into one launch == T x (greedy_actions, step), bit for bit
+    for N, M, coop in ((20, 10, 0.0), (20, 10, 0.3), (7, 4, 0.0)):
+        cfg = uavtrack.EnvConfig(n_envs=96, n_uav=N, m_targets=M, cooperative=coop, x_max=900.0, y_max=800.0, env_offset=5)
+        a, b = uavtrack.BatchedUavEnv(cfg), uavtrack.BatchedUavEnv(cfg)
+        a.reset(seed=4); b.reset(seed=4)
+        T = 23
+        fused = a.run_greedy(T, seed=11)
+        for t in range(T):
+            act = b.greedy_actions(seed=11)
+            assert torch.equal(act, fused["actions"][t]), (N, t)
+            obs, rew, _ = b.step(act)
+            assert torch.equal(obs, fused["obs"][t]) and torch.equal(rew, fused["reward"][t])
+            assert torch.equal(b.info["covered"], fused["covered"][t])
+        sa, sb = a.get_state(), b.get_state()
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), k
     # closed loop with the library's own policy: graph replay == eager
     cfg = uavtrack.EnvConfig(n_envs=128, n_uav=20, m_targets=10)
     res = {}
