@@ -133,6 +133,16 @@ def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, en
     gather = None
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
         gather = lambda ep: uavtrack.gather_rollout_summary(ep, n_envs_total=total_envs)
+    # output buffers of every launch shape of the timed region exist before it starts (allocation is
+    # not part of a step): full rollouts and the remainder launch
+    import uavtrack._lib as _l
+    for T in {min(rollout, steps), steps % rollout} - {0}:
+        out[T] = dict(obs=torch.empty(T, B, args.n_uav, _l.OBS_DIM, device=device),
+                      reward=torch.empty(T, B, args.n_uav, device=device),
+                      terms=torch.empty(T, 3, B, args.n_uav, device=device),
+                      covered=torch.empty(T, B, dtype=torch.int32, device=device),
+                      done=torch.empty(T, B, dtype=torch.uint8, device=device),
+                      ep_sums=torch.empty(B, 5, device=device))
     env.reset(seed=args.seed)
     run_rollouts(env, actions, warmup, rollout, out, gather=gather)
     torch.cuda.synchronize(device)
