@@ -11,6 +11,7 @@ from .compat import Environment  # noqa: F401
 from .pmi import fold_pmi_state_dict  # noqa: F401
 from .sharding import shard_range, gather_rollout_summary  # noqa: F401
 from .rollout import ActorMLP, BatchedRollout, sample_actions  # noqa: F401
+from .export import uav_tracks_from_obs, save_uav_positions, save_covered_num  # noqa: F401
 from . import _lib  # noqa: F401
 
 __all__ = ["EnvConfig", "RewardMode", "BatchedUavEnv", "Environment", "fold_pmi_state_dict",

@@ -127,3 +127,26 @@ def test_shard_range_partitions_exactly():
                 assert o0 + c0 == o1
     with pytest.raises(ValueError):
         shard_range(8, 8, 8)
+
+
+def test_export_matches_reference_csv_layout(tmp_path):
+    """environment.py:229-244 layouts: u_xy rows are UAV-major then step; one covered count per step."""
+    from uavtrack.export import save_covered_num, save_uav_positions, uav_tracks_from_obs
+    T, B, N = 4, 3, 2
+    obs = np.zeros((T, B, N, 12), dtype=np.float32)
+    for t in range(T):
+        for i in range(N):
+            obs[t, 1, i, 9] = (100 * i + t) / 500.0       # x / dc
+            obs[t, 1, i, 10] = (7 * i + 2 * t) / 500.0    # y / dc
+    xs, ys = uav_tracks_from_obs(obs, 500.0, env_index=1)
+    assert xs.shape == (T, N) and abs(xs[3, 1] - 103) < 1e-3 and abs(ys[2, 1] - 11) < 1e-3
+    path = save_uav_positions(str(tmp_path), 5, xs, ys)
+    rows = np.loadtxt(path, delimiter=",", skiprows=1)
+    # what the reference computes: np.array([all_uav_xs, all_uav_ys]).transpose().reshape(-1, 2)
+    want = np.array([xs.tolist(), ys.tolist()]).transpose().reshape(-1, 2)
+    np.testing.assert_allclose(rows, want, atol=1e-3)
+    assert open(path).readline().strip() == "x,y" and rows.shape == (N * T, 2)
+    np.testing.assert_allclose(rows[:T, 0], [0, 1, 2, 3], atol=1e-3)        # UAV 0 over the steps first
+    cov = np.arange(T * B).reshape(T, B)
+    cpath = save_covered_num(str(tmp_path), 5, cov, env_index=2)
+    np.testing.assert_array_equal(np.loadtxt(cpath, skiprows=1), cov[:, 2])
