@@ -97,30 +97,38 @@ def make_env(uavtrack, args, B, device, env_offset=0):
     return env
 
 
-def run_rollouts(env, actions, steps, rollout, out, events=None, gather=None):
-    """Issue `steps` env steps as ceil(steps / rollout) launches; returns #launches."""
+def launch_plan(steps, rollout, horizon, ep_steps):
+    """Launch sizes for `steps` env steps: at most `rollout` steps per launch, never across an episode
+    end.  Returns ([T, ...], episode position afterwards)."""
+    plan = []
+    while steps > 0:
+        T = min(rollout, steps, horizon - ep_steps)
+        plan.append(T)
+        steps -= T
+        ep_steps = (ep_steps + T) % horizon
+    return plan, ep_steps
+
+
+def run_rollouts(env, actions, plan, ep_steps, out, events=None, gather=None):
+    """Issue the launches of `plan`; gathers the episode summaries and resets at every episode end."""
     import torch
-    done_steps, launches, ep_steps = 0, 0, 0
     horizon = env.cfg.horizon
-    while done_steps < steps:
-        T = min(rollout, steps - done_steps)
+    for T in plan:
         if events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        res = env.step_many(actions[:T], out=out.get(T))
+        res = env.step_many(actions[ep_steps:ep_steps + T], out=out.get(T))   # the episode's own action rows
         if events is not None:
             e1.record()
             events.append((e0, e1, T))
         out[T] = res
-        done_steps += T
-        launches += 1
         ep_steps += T
         if ep_steps >= horizon:               # end of an episode: gather summaries, start the next one
             if gather is not None:
                 gather(res["ep_sums"])
             env.reset(seed=42)
             ep_steps = 0
-    return launches
+    return len(plan)
 
 
 def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, env_offset=0, total_envs=None):
@@ -128,15 +136,19 @@ def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, en
     env = make_env(uavtrack, args, B, device, env_offset)
     na_total = env.cfg.na_total
     g = torch.Generator(device=device).manual_seed(args.seed + env_offset)
-    actions = torch.randint(0, na_total, (rollout, B, args.n_uav), dtype=torch.int32, device=device, generator=g)
+    rows = max(rollout, env.cfg.horizon)      # one pre-sampled action row per step of an episode
+    actions = torch.randint(0, na_total, (rows, B, args.n_uav), dtype=torch.int32, device=device, generator=g)
     out = {}
     gather = None
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
         gather = lambda ep: uavtrack.gather_rollout_summary(ep, n_envs_total=total_envs)
+    horizon = env.cfg.horizon
+    warm_plan, pos = launch_plan(warmup, rollout, horizon, 0)
+    timed_plan, _ = launch_plan(steps, rollout, horizon, pos)
     # output buffers of every launch shape of the timed region exist before it starts (allocation is
-    # not part of a step): full rollouts and the remainder launch
+    # not part of a step)
     import uavtrack._lib as _l
-    for T in {min(rollout, steps), steps % rollout} - {0}:
+    for T in set(timed_plan):
         out[T] = dict(obs=torch.empty(T, B, args.n_uav, _l.OBS_DIM, device=device),
                       reward=torch.empty(T, B, args.n_uav, device=device),
                       terms=torch.empty(T, 3, B, args.n_uav, device=device),
@@ -144,14 +156,14 @@ def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, en
                       done=torch.empty(T, B, dtype=torch.uint8, device=device),
                       ep_sums=torch.empty(B, 5, device=device))
     env.reset(seed=args.seed)
-    run_rollouts(env, actions, warmup, rollout, out, gather=gather)
+    run_rollouts(env, actions, warm_plan, 0, out, gather=gather)
     torch.cuda.synchronize(device)
     if gather is not None:
         dist.barrier()
     events = []
     pairs0 = env.pmi_pairs_scored() if args.reward == "pmi" else 0
     t0 = time.perf_counter()
-    launches = run_rollouts(env, actions, steps, rollout, out, events=events, gather=gather)
+    launches = run_rollouts(env, actions, timed_plan, pos, out, events=events, gather=gather)
     torch.cuda.synchronize(device)
     if gather is not None:
         dist.barrier()
