@@ -505,7 +505,9 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         const float4 *rowNew = uenv + pn * 3;
         const float4 *rowOld = uenv + (pn ^ 1) * 3;
         const v2f *tzrow = reinterpret_cast<const v2f *>(tzf + e * MP * 2);
-        constexpr bool kMask = (MODE == UAVTRACK_REWARD_PMI) && N_ > 0 && N_ <= 64;   // neighbour set fits one mask
+        // cooperative modes with N <= 64: the neighbour set (d <= dp on post-move poses) falls out of the peer
+        // sweep as one 64-bit mask
+        constexpr bool kMask = (MODE != UAVTRACK_REWARD_RAW) && N_ > 0 && N_ <= 64;
         unsigned long long nbmask = 0;
         if (active) {
             Acc acc;
@@ -566,7 +568,17 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         if (active) {
             float r = raw;
             if (MODE == UAVTRACK_REWARD_MEAN) {
-                if (p.coop != 0.0f) {   // uav.py:293-310; neighbours on post-move poses, self subtracted after
+                if (p.coop != 0.0f && kMask) {   // uav.py:293-310: walk the set bits of the neighbour mask, ascending j
+                    unsigned long long nb = nbmask & ~(1ull << i);
+                    float sum = 0.0f;
+                    const int ncnt_i = __popcll(nb);
+                    while (nb) {
+                        const int j = __ffsll((long long)nb) - 1;
+                        nb &= nb - 1;
+                        sum += rawl[e * (N + 1) + j];
+                    }
+                    r = ncnt_i ? (1.0f - p.coop) * raw + p.coop * sum / (float)ncnt_i : 0.0f;
+                } else if (p.coop != 0.0f) {   // any N: neighbours re-derived from the post-move poses, self subtracted after
                     v2f sum = splat(0.f), cnt = splat(0.f);
                     const v2f xi2 = splat(x), yi2 = splat(y), zi2 = splat(z);
                     const int NP = pairs_of(N_ > 0 ? N_ : N);
