@@ -93,12 +93,21 @@ class BatchedUavEnv:
                                             _ptr(obs), self._stream()), "uavtrack_reset")
         return obs
 
-    def step(self, actions, want_terms: bool = True, ep_sums: Optional[torch.Tensor] = None):
+    def step(self, actions, want_terms: bool = True, ep_sums: Optional[torch.Tensor] = None,
+             out_obs: Optional[torch.Tensor] = None, out_reward: Optional[torch.Tensor] = None):
         """`ep_sums` [B, 5] (float32, this device): running episode accumulators the kernel adds
-        this step's contribution to (train.py:181-192)."""
+        this step's contribution to (train.py:181-192).  `out_obs` / `out_reward`: caller-owned
+        buffers the kernel writes instead of fresh tensors (static graph I/O)."""
         a = self._actions(actions, (self.B, self.N))
-        obs = self._empty((self.B, self.N, _lib.OBS_DIM), torch.float32)
-        reward = self._empty((self.B, self.N), torch.float32)
+
+        def take(buf, shape):
+            if buf is None:
+                return self._empty(shape, torch.float32)
+            if tuple(buf.shape) != shape or buf.dtype != torch.float32 or not buf.is_contiguous() or buf.device != self.device:
+                raise ValueError(f"output buffer must be a contiguous float32 {shape} tensor on {self.device}")
+            return buf
+        obs = take(out_obs, (self.B, self.N, _lib.OBS_DIM))
+        reward = take(out_reward, (self.B, self.N))
         terms = self._empty((3, self.B, self.N), torch.float32) if want_terms else None
         covered = self._empty((self.B,), torch.int32)
         done = self._empty((self.B,), torch.uint8)

@@ -61,9 +61,9 @@ class BatchedRollout:
         else:
             with torch.no_grad():
                 actions = self.select(self.policy(self.obs))
-        obs, reward, _ = self.env.step(actions, ep_sums=self.ep)   # the kernel adds to the accumulators
-        self.obs.copy_(obs)
-        self.last_reward.copy_(reward)
+        # the kernel writes the static buffers in place and adds to the accumulators: no torch op per step.
+        # (The policy has consumed self.obs before the step kernel overwrites it: same stream.)
+        self.env.step(actions, ep_sums=self.ep, out_obs=self.obs, out_reward=self.last_reward)
 
     def _capture(self):
         # warm up on a side stream (allocator pools, lazy inits), then capture k steps
