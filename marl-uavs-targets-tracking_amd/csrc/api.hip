@@ -44,9 +44,7 @@ hipError_t dmalloc(T **p, size_t n)
 
 void free_state(uavtrack_env *env)
 {
-    StateBlock &s = env->state;
-    void *ptrs[] = {s.ux, s.uy, s.uz, s.uh, s.ua, s.tx, s.ty, s.tz, s.th, s.step_count,
-                    env->d_state, env->pmi.blob, env->pairs, env->pair_count, env->pair_total, env->scores, env->pose,
+    void *ptrs[] = {env->slab, env->pmi.blob, env->pairs, env->pair_count, env->pair_total, env->scores, env->pose,
                     env->obs_tmp, env->terms_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -111,7 +109,7 @@ int ensure_pmi_scratch(uavtrack_env *env, int32_t steps, hipStream_t st)
     return 0;
 }
 
-void fold_constants(const uavtrack_config &c, StepParams &p, StateBlock &sb)
+void fold_constants(const uavtrack_config &c, StepParams &p, float *climb_c, float *climb_s)
 {
     p.B = c.n_envs; p.N = c.n_uav; p.M = c.m_targets;
     p.na = c.na; p.na_total = c.na * c.nc; p.horizon = c.horizon;
@@ -140,8 +138,8 @@ void fold_constants(const uavtrack_config &c, StepParams &p, StateBlock &sb)
     for (int k = 0; k < UAVTRACK_MAX_CLIMB; ++k) {
         double g = 0.0;
         if (c.nc > 1 && k < c.nc) g = (2.0 * k - (c.nc - 1)) * c.u_g_max / (double)(c.nc - 1);
-        sb.climb_c[k] = (float)std::cos(g);
-        sb.climb_s[k] = (float)std::sin(g);
+        climb_c[k] = (float)std::cos(g);
+        climb_s[k] = (float)std::sin(g);
     }
 }
 
@@ -177,8 +175,8 @@ int uavtrack_create(const uavtrack_config *cfg, uavtrack_env **out)
     if (!env) return fail("uavtrack_create: out of host memory");
     env->cfg = *cfg;
     memset(&env->base, 0, sizeof env->base);
-    memset(&env->state, 0, sizeof env->state);
-    fold_constants(*cfg, env->base, env->state);
+    float climb[2 * UAVTRACK_MAX_CLIMB];
+    fold_constants(*cfg, env->base, climb, climb + UAVTRACK_MAX_CLIMB);
     env->geo = plan_geometry(*cfg);
     if (env->geo.wgs == 0) {
         delete env;
@@ -192,24 +190,13 @@ int uavtrack_create(const uavtrack_config *cfg, uavtrack_env **out)
                     cfg->m_targets);
     }
 
-    StateBlock &s = env->state;
-    const size_t BN = (size_t)cfg->n_envs * cfg->n_uav, BM = (size_t)cfg->n_envs * cfg->m_targets;
-    hipError_t err = hipSuccess;
-    auto keep = [&](hipError_t r) { if (err == hipSuccess) err = r; };
-    keep(dmalloc(&s.ux, BN)); keep(dmalloc(&s.uy, BN)); keep(dmalloc(&s.uh, BN)); keep(dmalloc(&s.ua, BN));
-    keep(dmalloc(&s.tx, BM)); keep(dmalloc(&s.ty, BM)); keep(dmalloc(&s.th, BM));
-    keep(dmalloc(&s.step_count, (size_t)cfg->n_envs));
-    if (cfg->dim == 3) { keep(dmalloc(&s.uz, BN)); keep(dmalloc(&s.tz, BM)); }
+    const size_t nfl = state_slab_floats(cfg->n_envs, cfg->n_uav, cfg->m_targets, cfg->dim == 3);
+    hipError_t err = dmalloc(&env->slab, nfl);
+    if (err == hipSuccess) err = hipMemset(env->slab, 0, nfl * sizeof(float));
     if (err == hipSuccess) {
-        keep(hipMemset(s.ux, 0, BN * 4)); keep(hipMemset(s.uy, 0, BN * 4)); keep(hipMemset(s.uh, 0, BN * 4));
-        keep(hipMemset(s.ua, 0, BN * 4));
-        keep(hipMemset(s.tx, 0, (BM ? BM : 1) * 4)); keep(hipMemset(s.ty, 0, (BM ? BM : 1) * 4));
-        keep(hipMemset(s.th, 0, (BM ? BM : 1) * 4));
-        keep(hipMemset(s.step_count, 0, (size_t)cfg->n_envs * 4));
-        if (cfg->dim == 3) { keep(hipMemset(s.uz, 0, BN * 4)); keep(hipMemset(s.tz, 0, (BM ? BM : 1) * 4)); }
-        keep(dmalloc(&env->d_state, 1));
-        if (err == hipSuccess) keep(hipMemcpy(env->d_state, &env->state, sizeof(StateBlock), hipMemcpyHostToDevice));
-        env->base.st = env->d_state;
+        env->state = state_view(env->slab, cfg->n_envs, cfg->n_uav, cfg->m_targets, cfg->dim == 3);
+        err = hipMemcpy(env->state.climb_c, climb, sizeof climb, hipMemcpyHostToDevice);
+        env->base.slab = env->slab;
     }
     if (err != hipSuccess) {
         free_state(env);

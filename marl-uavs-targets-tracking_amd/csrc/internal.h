@@ -15,19 +15,45 @@ constexpr int kMaxWorkgroup = 512;   // __launch_bounds__ of the rollout kernel
 
 // Kernel arguments of one rollout launch (T >= 1 steps).  All pointers are device
 // pointers.  Derived constants are computed once on the host in fp64, then cast.
-// Per-handle block that lives in device memory: the kernel reaches the state arrays through
-// one pointer instead of carrying 10 pointers (20 SGPRs) through the whole step loop.
+// The state arrays live in ONE device slab at offsets that follow from (B, N, M, dim), so the kernel
+// carries a single base pointer (2 SGPRs instead of 20 through the whole step loop) and derives the
+// rest with scalar adds -- no dependent pointer load at the start of a launch.  Slab order (4-byte
+// units): ux uy uh ua [uz] (B*N each), tx ty th [tz] (B*M each), step_count (B), climb_c climb_s (8 each).
 struct StateBlock {
     // state, SoA over (env, uav) and (env, target); updated in place
     float *ux, *uy, *uz, *uh;
     int32_t *ua;
     float *tx, *ty, *tz, *th;
     int32_t *step_count;
-    float climb_c[UAVTRACK_MAX_CLIMB], climb_s[UAVTRACK_MAX_CLIMB];   // cos/sin of the climb angles
+    float *climb_c, *climb_s;   // cos/sin of the climb angles (UAVTRACK_MAX_CLIMB each)
 };
 
+__host__ __device__ inline StateBlock state_view(float *slab, int B, int N, int M, bool z3)
+{
+    const size_t BN = (size_t)B * N, BM = (size_t)B * M;
+    StateBlock v;
+    float *f = slab;
+    v.ux = f; f += BN;
+    v.uy = f; f += BN;
+    v.uh = f; f += BN;
+    v.ua = reinterpret_cast<int32_t *>(f); f += BN;
+    v.uz = z3 ? f : nullptr; if (z3) f += BN;
+    v.tx = f; f += BM;
+    v.ty = f; f += BM;
+    v.th = f; f += BM;
+    v.tz = z3 ? f : nullptr; if (z3) f += BM;
+    v.step_count = reinterpret_cast<int32_t *>(f); f += B;
+    v.climb_c = f; f += UAVTRACK_MAX_CLIMB;
+    v.climb_s = f;
+    return v;
+}
+inline size_t state_slab_floats(int B, int N, int M, bool z3)
+{
+    return ((size_t)B * N) * (z3 ? 5 : 4) + ((size_t)B * M) * (z3 ? 4 : 3) + (size_t)B + 2 * UAVTRACK_MAX_CLIMB;
+}
+
 struct StepParams {
-    const StateBlock *st;
+    float *slab;             // state slab, see state_view()
     // per-step I/O, leading [T] axis
     const int32_t *actions;
     float *obs, *reward, *terms;
@@ -76,8 +102,8 @@ struct Geometry {
 struct uavtrack_env {
     uavtrack_config cfg;
     uavtrack::StepParams base;   // constants filled at create
-    uavtrack::StateBlock state;  // host copy of the device-resident block
-    uavtrack::StateBlock *d_state = nullptr;
+    float *slab = nullptr;       // the one device allocation behind `state`
+    uavtrack::StateBlock state;  // pointers into the slab (host-side view)
     uavtrack::Geometry geo;
     uavtrack::PmiWeights pmi;
     // MAAC-R scratch for `pmi_steps_cap` steps of deferred scoring (rewards never feed back into the

@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     int pn = 0;                                   // which table copy is "post-move" this step
 
     // ---- load state once
-    const StateBlock &S = *p.st;
+    const StateBlock S = state_view(p.slab, p.B, N, M, Z3);
     if (active) {
         x = S.ux[g]; y = S.uy[g]; h = S.uh[g]; a_prev = S.ua[g];
         if (Z3) z = S.uz[g];
