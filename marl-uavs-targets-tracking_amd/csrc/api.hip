@@ -123,6 +123,18 @@ void fold_constants(const uavtrack_config &c, StepParams &p, float *climb_c, flo
     p.dp2 = (float)(c.dp * c.dp);
     p.dc2 = (float)(c.dc * c.dc);
     p.two_dp2 = (float)(4.0 * c.dp * c.dp);
+    {   // pk_le_mask constants: S = 2^k with ulp(smallest K) * S >= 1
+        const float kmin = fminf(p.dp2, fminf(p.dc2, p.two_dp2));
+        int e = 0;
+        std::frexp(kmin, &e);                       // kmin = m * 2^e, m in [0.5, 1): ulp = 2^(e - 24)
+        int k = 24 - e;
+        if (k < 0) k = 0;
+        const float S = std::ldexp(1.0f, k);
+        p.le_neg_scale = -S;
+        p.le_dp2 = std::nextafterf(p.dp2, INFINITY) * S;
+        p.le_dc2 = std::nextafterf(p.dc2, INFINITY) * S;
+        p.le_two_dp2 = std::nextafterf(p.two_dp2, INFINITY) * S;
+    }
     p.vratio = (float)(c.t_v_max / c.u_v_max);
     p.inv_na_total = (float)(1.0 / (double)(c.na * c.nc));
     const double log2e = 1.4426950408889634;
@@ -177,7 +189,11 @@ int uavtrack_create(const uavtrack_config *cfg, uavtrack_env **out)
     memset(&env->base, 0, sizeof env->base);
     float climb[2 * UAVTRACK_MAX_CLIMB];
     fold_constants(*cfg, env->base, climb, climb + UAVTRACK_MAX_CLIMB);
-    env->geo = plan_geometry(*cfg);
+    if (!std::isfinite(env->base.le_dp2) || !std::isfinite(env->base.le_dc2) || !std::isfinite(env->base.le_two_dp2)) {
+        delete env;
+        return fail("uavtrack_create: dp=%g and dc=%g are too far apart for the fp32 range tests", cfg->dp, cfg->dc);
+    }
+    env->geo = plan_geometry(*cfg, prop.multiProcessorCount * 4);
     if (env->geo.wgs == 0) {
         delete env;
         return fail("uavtrack_create: no workgroup geometry for n_uav=%d", cfg->n_uav);

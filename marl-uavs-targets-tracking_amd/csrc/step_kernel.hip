@@ -69,6 +69,25 @@ __device__ __forceinline__ float fast_rcp(float v) { return __builtin_amdgcn_rcp
 __device__ __forceinline__ float fast_exp2(float v) { return __builtin_amdgcn_exp2f(v); }
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f splat(float v) { return (v2f){v, v}; }
+// Range test of two squared distances in one instruction: 1.0 where d2 <= K else 0.0, as
+// clamp(fma(d2, -S, nextafter(K) * S)) with S a power of two >= 1 / ulp(K) (fold_constants).  The
+// FMA rounds the exact value once, so its sign is exact; the smallest positive value is
+// ulp(K) * S >= 1 and clamps to exactly 1; overflow gives -inf -> 0; NaN clamps to 0 (DX10 clamp),
+// the same as the compare it replaces.  There is no packed compare/select, so this replaces
+// 2 v_cmp + 2 v_cndmask.
+#ifndef UAVTRACK_LE_ASM
+#define UAVTRACK_LE_ASM 1
+#endif
+__device__ __forceinline__ v2f pk_le_mask(v2f d2, v2f neg_scale, float c)
+{
+    v2f r;
+    const v2f c2 = splat(c);
+    // (clang treats inline asm as convergent in HIP, which blocks partial unrolling of the sweeps: the
+    // Makefile builds this file with -fno-convergent-functions; every cross-lane operation here is a
+    // builtin that carries its own convergence)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(d2), "v"(neg_scale), "s"(c2));
+    return r;
+}
 
 // The squared distance every range test of the path uses (also in pmi_kernel.hip): dx*dx
 // rounded, then one fma.  Scalar and packed forms give identical bits.
@@ -167,6 +186,7 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
                                            unsigned long long &nbmask)
 {
     const v2f xi2 = splat(xi), yi2 = splat(yi), zi2 = splat(zi);
+    const v2f nscale = splat(p.le_neg_scale);
     const int NP = pairs_of(N_ > 0 ? N_ : N), MP = pairs_of(M_ > 0 ? M_ : M);
     // Up to 10 pair rows (N <= 20) the whole peer sweep is unrolled: measured 4-7 % faster than
     // unrolling by 5 and, with the pair layout, still 127 VGPRs; larger N keeps the partial unroll.
@@ -182,7 +202,11 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
         v2f d2 = pk_fma(dy, dy, dx * dx);
         if (Z3) { const v2f dz = tzrow[kp] - zi2; d2 = pk_fma(dz, dz, d2); }
         const v2f dist = {fast_sqrt(d2.x), fast_sqrt(d2.y)};
+#if UAVTRACK_LE_ASM
+        const v2f mm = pk_le_mask(d2, nscale, p.le_dp2);
+#else
         const v2f mm = {d2.x <= p.dp2 ? 1.0f : 0.0f, d2.y <= p.dp2 ? 1.0f : 0.0f};
+#endif
         sx = pk_fma(mm, dx, sx);
         sy = pk_fma(mm, dy, sy);
         sc = pk_fma(mm, (v2f){q1.x, q1.y}, sc);
@@ -223,8 +247,13 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
         if (NB)   // MAAC-R (N <= 64): neighbours (d <= dp on post-move poses, uav.py:278) as a bit mask
             nbmask |= ((unsigned long long)(d2n.x <= p.dp2 ? 1u : 0u) | (unsigned long long)(d2n.y <= p.dp2 ? 2u : 0u)) << (2 * jp);
         const v2f w = pk_fma((v2f){fast_sqrt(d2n.x), fast_sqrt(d2n.y)}, splat(-p.exp_k1), splat(p.exp_k0));
+#if UAVTRACK_LE_ASM
+        dup = pk_fma(pk_le_mask(d2n, nscale, p.le_two_dp2), (v2f){fast_exp2(w.x), fast_exp2(w.y)}, dup);
+        const v2f mm = pk_le_mask(d2m, nscale, p.le_dc2);
+#else
         dup += (v2f){d2n.x <= p.two_dp2 ? fast_exp2(w.x) : 0.0f, d2n.y <= p.two_dp2 ? fast_exp2(w.y) : 0.0f};
         const v2f mm = {d2m.x <= p.dc2 ? 1.0f : 0.0f, d2m.y <= p.dc2 ? 1.0f : 0.0f};
+#endif
         sx = pk_fma(mm, dxm, sx);
         sy = pk_fma(mm, dym, sy);
         sc = pk_fma(mm, (v2f){m1.x, m1.y}, sc);
@@ -758,34 +787,46 @@ KernelFn pick_kernel(int N, int M, int mode, bool z3, int *specialised, bool gre
 
 }  // namespace
 
-Geometry plan_geometry(const uavtrack_config &cfg)
+Geometry plan_geometry(const uavtrack_config &cfg, int n_simd)
 {
     Geometry g;
     const int N = cfg.n_uav;
     int best = 0;
-    double best_util = -1.0;
     int forced = 0;
     if (const char *s = getenv("UAVTRACK_WGS")) forced = atoi(s);
     // Whole multiples of 4 waves (or fewer than 4) keep the four SIMDs of a CU evenly loaded:
     // 320-thread groups (100 % lane use at N = 20) measured 26 % slower than 256 at a
-    // chip-filling batch.  Among the candidates take the best lane utilisation; ties go to
-    // the size that measured fastest (256, then 128, 512, 64).
-    static const int kCandidates[] = {256, 128, 512, 64};
+    // chip-filling batch.  Take the best lane utilisation (5 % band).  Inside the band the
+    // batch decides (measured, N = 20 M = 10): up to ~3 waves per SIMD single-wave groups win
+    // (no cross-wave barrier on a step whose waves mostly run alone on their SIMD: 4096 envs
+    // 0.689 ms vs 0.751 ms per 200 steps); past that 4-wave groups win (65 536 envs 39.6 vs 33.9 G).
+    static const int kLarge[] = {256, 128, 512, 64};
+    static const int kSmall[] = {64, 128, 256, 512};
     auto feasible = [&](int wgs) {
         const int E = wgs / N;
         return E >= 1 && lds_bytes_for(E, N, cfg.m_targets, cfg.dim == 3) <= 64 * 1024;   // e.g. N = 1, many targets
+    };
+    auto util_of = [&](int wgs) {
+        const int E = wgs / N;
+        const int Euse = E < cfg.n_envs ? E : cfg.n_envs;
+        return (double)Euse * N / wgs;
     };
     // UAVTRACK_WGS (experiments) is honoured when that geometry is feasible, else ignored
     if (forced >= 64 && forced <= kMaxWorkgroup && forced % 64 == 0 && feasible(forced)) {
         best = forced;
     } else {
-        for (int wgs : kCandidates) {
-            if (!feasible(wgs)) continue;
-            const int E = wgs / N;
-            const int Euse = E < cfg.n_envs ? E : cfg.n_envs;
-            const double util = (double)Euse * N / wgs;
-            if (util > best_util + 0.05) { best_util = util; best = wgs; }
+        double best_util = -1.0;
+        for (int wgs : kLarge)
+            if (feasible(wgs) && util_of(wgs) > best_util) best_util = util_of(wgs);
+        bool small_grid = false;
+        if (feasible(64)) {
+            const long waves = (cfg.n_envs + 64 / N - 1) / (64 / N);
+            small_grid = waves <= 3L * (n_simd > 0 ? n_simd : 1024);
         }
+        // (the band is a little wider on a small grid: N = 10 at 4096 envs measured 0.409 ms with
+        // 60/64 lanes in use against 0.435 ms with 250/256)
+        for (int wgs : small_grid ? kSmall : kLarge)
+            if (feasible(wgs) && util_of(wgs) >= best_util - (small_grid ? 0.07 : 0.05)) { best = wgs; break; }
     }
     if (!best) return g;
     g.wgs = best;
