@@ -78,6 +78,7 @@ __device__ __forceinline__ v2f splat(float v) { return (v2f){v, v}; }
 #ifndef UAVTRACK_LE_ASM
 #define UAVTRACK_LE_ASM 1
 #endif
+
 __device__ __forceinline__ v2f pk_le_mask(v2f d2, v2f neg_scale, float c)
 {
     v2f r;
