@@ -357,13 +357,13 @@ def main():
             # closed loop: actor forward [B*N,12] -> sample -> uavtrack_step per step, eager
             # launches vs the same steps replayed from a HIP graph
             torch.manual_seed(args.seed)
-            actor = uavtrack.ActorMLP(action_dim=12 * (3 if args.dim == 3 else 1)).to(device)
+            actor = uavtrack.ActorMLP(hidden_dim=128, action_dim=12 * (3 if args.dim == 3 else 1)).to(device)
             cl = {}
-            modes = ("eager", "graph") + (("greedy_graph",) if args.dim == 2 else ())
+            modes = ("eager", "graph") + (("actor_graph", "greedy_graph") if args.dim == 2 else ())
             for mode in modes:
                 env = make_env(uavtrack, args, B, device)
                 ro = uavtrack.BatchedRollout(env, "greedy" if mode == "greedy_graph" else actor, steps_per_graph=10,
-                                             use_graph=(mode != "eager"))
+                                             use_graph=(mode != "eager"), device_actor=(mode == "actor_graph"))
                 ro.reset(seed=args.seed)
                 ro.run(40)
                 torch.cuda.synchronize(device)
@@ -386,10 +386,25 @@ def main():
                 dt = time.perf_counter() - t0
                 cl["greedy_fused"] = {"agent_steps_per_s": B * N * 1000 / dt, "ms_per_step": dt * 1e3 / 1000}
                 env.close()
-            cl["note"] = ("reference-shaped shared actor (12-256-12 softmax, random init) + categorical sample + "
-                          "uavtrack_step_accumulate, all on device; graph = 10 steps per HIP-graph replay; greedy_graph = the "
-                          "reference's C-METHOD baseline policy (uav.py:324-369) from the library's own kernel instead of "
-                          "the torch actor; greedy_fused = uavtrack_run_greedy, policy and step of a whole 200-step episode in one launch")
+                # actor + environment of a whole 200-step episode in one launch (uavtrack_run_actor)
+                env = make_env(uavtrack, args, B, device)
+                env.set_actor(actor)
+                out = env.run_actor(200, env.reset(seed=args.seed), seed=args.seed, want_terms=False)
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    out = env.run_actor(200, env.reset(seed=args.seed), seed=args.seed, want_terms=False, out=out)
+                torch.cuda.synchronize(device)
+                dt = time.perf_counter() - t0
+                cl["actor_fused"] = {"agent_steps_per_s": B * N * 1000 / dt, "ms_per_step": dt * 1e3 / 1000}
+                env.close()
+            cl["note"] = ("reference-shaped shared actor (FnnPolicyNet 12-128-12 softmax as in configs/MAAC.yaml, random "
+                          "init) + categorical sample + uavtrack_step_accumulate, all on device; eager/graph = the actor "
+                          "forward and the sample as PyTorch ops, graph = 10 steps per HIP-graph replay; actor_graph = the same "
+                          "with the library's own actor kernel (uavtrack_actor_actions); actor_fused = uavtrack_run_actor, "
+                          "actor and step of a whole 200-step episode in one launch (the rollout of train.operate_epoch); "
+                          "greedy_graph / greedy_fused = the same two forms with the reference's C-METHOD baseline policy "
+                          "(uav.py:324-369) instead of the actor")
             line["closed_loop"] = cl
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)

@@ -170,6 +170,37 @@ int uavtrack_run_greedy(uavtrack_env *env, int32_t T, uint64_t seed, int32_t *ac
                         float *obs, float *reward, float *terms,
                         int32_t *covered, uint8_t *done, float *ep_sums, void *stream);
 
+/* ---- the learner's shared actor, run on the device next to the environment ----
+ * The reference's train.operate_epoch calls ActorCritic.take_action once per UAV per step
+ * (train.py:165-172 -> actor_critic.py:138-148): a batch-1 forward of FnnPolicyNet
+ * (actor_critic.py:85-98: Linear(12,H) - ReLU - Linear(H,na) - softmax) and Categorical(probs).sample(),
+ * with a host round trip each.  These three entry points keep that loop on the GPU. */
+enum { UAVTRACK_ACTOR_SAMPLE = 0,   /* Categorical(probs).sample(): inverse CDF at a Philox uniform */
+       UAVTRACK_ACTOR_ARGMAX = 1 }; /* deterministic evaluation: most probable action, lowest index on ties */
+
+/* Uploads FnnPolicyNet's parameters (HOST pointers, fp32, torch layouts): w1 [hidden][12] = fc1.weight,
+ * b1 [hidden] = fc1.bias, w2 [na*nc][hidden] = fc2.weight, b2 [na*nc] = fc2.bias.  na*nc <= 12 (the
+ * reference's action space, configs: na = 12).  w1 = NULL removes the actor.  Synchronises `stream`. */
+int uavtrack_set_actor_weights(uavtrack_env *env, const float *w1, const float *b1,
+                               const float *w2, const float *b2, int32_t hidden, void *stream);
+
+/* take_action for every UAV: obs [B][N][12] (what get_local_state returned, i.e. the obs output of the
+ * previous step / reset) -> actions [B][N] int32, and, if probs != NULL, the policy's probabilities
+ * probs [B][N][na*nc].  Draws are keyed by (seed, env_offset + b, step_count[b], uav). */
+int uavtrack_actor_actions(uavtrack_env *env, const float *obs, uint64_t seed, int32_t mode,
+                           int32_t *actions, float *probs, void *stream);
+
+/* The rollout half of train.operate_epoch (train.py:160-192) in ONE launch: per step every UAV's action
+ * comes from the actor applied to its own previous observation (held in registers), then
+ * Environment.step runs -- T closed-loop steps with the state on chip.  obs_in [B][N][12] is the
+ * observation the policy sees at the first step.  Bitwise identical to T x (uavtrack_actor_actions,
+ * uavtrack_step).  actions_out (nullable) [T][B][N]; the other outputs are those of uavtrack_step_many,
+ * i.e. the (state, action, reward, next_state) transitions of train.py:176-180 land in
+ * obs[t-1] / actions_out[t] / reward[t] / obs[t].  Reward modes RAW / MEAN. */
+int uavtrack_run_actor(uavtrack_env *env, int32_t T, uint64_t seed, int32_t mode, const float *obs_in,
+                       int32_t *actions_out, float *obs, float *reward, float *terms,
+                       int32_t *covered, uint8_t *done, float *ep_sums, void *stream);
+
 /* MAAC-R accounting for reports: out[0] = neighbour pairs scored by the PMI network since
  * the weights were set (each unordered pair once per step).  Synchronises `stream`. */
 int uavtrack_pmi_pairs_scored(uavtrack_env *env, uint64_t *out, void *stream);

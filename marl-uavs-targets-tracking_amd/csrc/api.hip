@@ -3,6 +3,7 @@
 // happens on the host and there is no CPU fallback.
 
 #include "internal.h"
+#include "actor.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -44,7 +45,7 @@ hipError_t dmalloc(T **p, size_t n)
 
 void free_state(uavtrack_env *env)
 {
-    void *ptrs[] = {env->slab, env->pmi.blob, env->pairs, env->pair_count, env->pair_total, env->scores, env->pose,
+    void *ptrs[] = {env->slab, env->pmi.blob, env->actor_w, env->pairs, env->pair_count, env->pair_total, env->scores, env->pose,
                     env->obs_tmp, env->terms_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -431,7 +432,7 @@ int uavtrack_run_greedy(uavtrack_env *env, int32_t T, uint64_t seed, int32_t *ac
     p.pairs = nullptr; p.pair_count = nullptr; p.ep_accumulate = 0;
     p.env_offset = env->cfg.env_offset;
     p.greedy_k0 = (uint32_t)seed; p.greedy_k1 = (uint32_t)(seed >> 32);
-    HIP_TRY(launch_rollout(env, p, static_cast<hipStream_t>(stream), true));
+    HIP_TRY(launch_rollout(env, p, static_cast<hipStream_t>(stream), kPolicyGreedy));
     return 0;
 }
 
@@ -442,6 +443,88 @@ int uavtrack_greedy_actions(uavtrack_env *env, uint64_t seed, int32_t *actions, 
     if (env->cfg.dim != 2) return fail("uavtrack_greedy_actions: the reference baseline is planar (dim must be 2)");
     HIP_TRY(hipSetDevice(env->cfg.device_id));
     HIP_TRY(launch_greedy(env, seed, actions, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int uavtrack_set_actor_weights(uavtrack_env *env, const float *w1, const float *b1, const float *w2, const float *b2,
+                               int32_t hidden, void *stream)
+{
+    if (!env) return fail("uavtrack_set_actor_weights: null handle");
+    HIP_TRY(hipSetDevice(env->cfg.device_id));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipStreamSynchronize(st));
+    if (!w1) {
+        if (env->actor_w) (void)hipFree(env->actor_w);
+        env->actor_w = nullptr; env->actor_hidden = 0;
+        return 0;
+    }
+    if (!b1 || !w2 || !b2) return fail("uavtrack_set_actor_weights: b1, w2 and b2 must not be null");
+    const int A = env->cfg.na * env->cfg.nc;
+    if (A > kActorMaxActions)
+        return fail("uavtrack_set_actor_weights: na*nc = %d actions; the device actor is built for the reference's "
+                    "action space (<= %d)", A, kActorMaxActions);
+    if (hidden < 1 || hidden > 4096) return fail("uavtrack_set_actor_weights: hidden %d out of range [1, 4096]", hidden);
+    const size_t n = actor_blob_floats(hidden);
+    std::vector<float> blob(n, 0.0f);
+    for (int h = 0; h < hidden; ++h) {
+        float *row = blob.data() + (size_t)h * kActorRow;
+        for (int k = 0; k < UAVTRACK_OBS_DIM; ++k) row[k] = w1[(size_t)h * UAVTRACK_OBS_DIM + k];
+        row[12] = b1[h];
+        for (int j = 0; j < A; ++j) row[kActorW2 + j] = w2[(size_t)j * hidden + h];
+    }
+    for (int j = 0; j < A; ++j) blob[(size_t)hidden * kActorRow + j] = b2[j];
+    if (env->actor_hidden != hidden) {
+        if (env->actor_w) (void)hipFree(env->actor_w);
+        env->actor_w = nullptr; env->actor_hidden = 0;
+        HIP_TRY(dmalloc(&env->actor_w, n));
+    }
+    HIP_TRY(hipMemcpyAsync(env->actor_w, blob.data(), n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    env->actor_hidden = hidden;
+    return 0;
+}
+
+int uavtrack_actor_actions(uavtrack_env *env, const float *obs, uint64_t seed, int32_t mode, int32_t *actions,
+                           float *probs, void *stream)
+{
+    if (!env) return fail("uavtrack_actor_actions: null handle");
+    if (!obs || !actions) return fail("uavtrack_actor_actions: obs and actions must not be null");
+    if (!env->actor_w) return fail("uavtrack_actor_actions: needs uavtrack_set_actor_weights first");
+    if (mode != UAVTRACK_ACTOR_SAMPLE && mode != UAVTRACK_ACTOR_ARGMAX)
+        return fail("uavtrack_actor_actions: mode %d is neither UAVTRACK_ACTOR_SAMPLE nor UAVTRACK_ACTOR_ARGMAX", mode);
+    HIP_TRY(hipSetDevice(env->cfg.device_id));
+    HIP_TRY(launch_actor(env, obs, seed, mode, actions, probs, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int uavtrack_run_actor(uavtrack_env *env, int32_t T, uint64_t seed, int32_t mode, const float *obs_in,
+                       int32_t *actions_out, float *obs, float *reward, float *terms, int32_t *covered,
+                       uint8_t *done, float *ep_sums, void *stream)
+{
+    if (!env) return fail("uavtrack_run_actor: null handle");
+    if (T < 1) return fail("uavtrack_run_actor: T must be >= 1 (got %d)", T);
+    if (!reward) return fail("uavtrack_run_actor: reward is null");
+    if (!obs_in) return fail("uavtrack_run_actor: obs_in is null (the observation the policy sees at the first step)");
+    if (!env->actor_w) return fail("uavtrack_run_actor: needs uavtrack_set_actor_weights first");
+    if (mode != UAVTRACK_ACTOR_SAMPLE && mode != UAVTRACK_ACTOR_ARGMAX)
+        return fail("uavtrack_run_actor: mode %d is neither UAVTRACK_ACTOR_SAMPLE nor UAVTRACK_ACTOR_ARGMAX", mode);
+    if (env->cfg.reward_mode == UAVTRACK_REWARD_PMI)
+        return fail("uavtrack_run_actor: reward modes RAW / MEAN only; with MAAC-R alternate uavtrack_actor_actions "
+                    "and uavtrack_step (its scoring is deferred per launch)");
+    if (obs_in == obs && T > 1)
+        return fail("uavtrack_run_actor: obs_in must not alias obs when T > 1 (obs[0] is written while other "
+                    "workgroups may still read obs_in)");
+    HIP_TRY(hipSetDevice(env->cfg.device_id));
+    StepParams p = env->base;
+    p.T = T;
+    p.actions = nullptr; p.actions_out = actions_out;
+    p.obs = obs; p.reward = reward; p.terms = terms; p.pose_out = nullptr;
+    p.covered = covered; p.done = done; p.ep_sums = ep_sums;
+    p.pairs = nullptr; p.pair_count = nullptr; p.ep_accumulate = 0;
+    p.env_offset = env->cfg.env_offset;
+    p.greedy_k0 = (uint32_t)seed; p.greedy_k1 = (uint32_t)(seed >> 32);
+    p.obs_in = obs_in; p.actor_w = env->actor_w; p.actor_hidden = env->actor_hidden; p.actor_mode = mode;
+    HIP_TRY(launch_rollout(env, p, static_cast<hipStream_t>(stream), kPolicyActor));
     return 0;
 }
 

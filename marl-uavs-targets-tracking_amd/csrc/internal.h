@@ -69,7 +69,11 @@ struct StepParams {
     // fused greedy rollout (uavtrack_run_greedy): actions come from the in-kernel baseline policy
     int32_t *actions_out;    // [T][B][N], nullable
     int64_t env_offset;
-    uint32_t greedy_k0, greedy_k1;
+    uint32_t greedy_k0, greedy_k1;   // policy seed (greedy and actor rollouts)
+    // fused actor rollout (uavtrack_run_actor): actions come from the in-kernel policy network (actor.h)
+    const float *obs_in;     // [B][N][12] observation seen at the first step
+    const float *actor_w;    // packed weight blob
+    int32_t actor_hidden, actor_mode;
     // constants
     float x_max, y_max, z_max;
     float dtv_u, dtv_t;          // dt * v_max of UAVs / targets
@@ -107,6 +111,8 @@ struct uavtrack_env {
     uavtrack::StateBlock state;  // pointers into the slab (host-side view)
     uavtrack::Geometry geo;
     uavtrack::PmiWeights pmi;
+    float *actor_w = nullptr;    // device blob of uavtrack_set_actor_weights (actor.h layout)
+    int32_t actor_hidden = 0;
     // MAAC-R scratch for `pmi_steps_cap` steps of deferred scoring (rewards never feed back into the
     // dynamics, so a chunk of steps is simulated first and all its pairs are scored in one launch):
     // pair list + counter, dense score matrix [steps][B][N][N], pose/raw [steps][B][N], and
@@ -123,7 +129,8 @@ namespace uavtrack {
 
 // step_kernel.hip
 Geometry plan_geometry(const uavtrack_config &cfg, int n_simd);
-hipError_t launch_rollout(const uavtrack_env *env, const StepParams &p, hipStream_t stream, bool greedy = false);
+enum { kPolicyGiven = 0, kPolicyGreedy = 1, kPolicyActor = 2 };   // where a rollout's actions come from
+hipError_t launch_rollout(const uavtrack_env *env, const StepParams &p, hipStream_t stream, int policy = kPolicyGiven);
 
 // pmi_kernel.hip
 bool pmi_hidden_supported(int hidden);
@@ -135,6 +142,8 @@ hipError_t launch_ep_sums(const uavtrack_env *env, int steps, const float *rewar
 
 // policy_kernel.hip
 hipError_t launch_greedy(const uavtrack_env *env, uint64_t seed, int32_t *actions, hipStream_t stream);
+hipError_t launch_actor(const uavtrack_env *env, const float *obs, uint64_t seed, int mode, int32_t *actions,
+                        float *probs, hipStream_t stream);
 
 // reset_kernel.hip
 hipError_t launch_reset(const uavtrack_env *env, uint64_t seed, uint32_t episode, float *obs,

@@ -1,6 +1,9 @@
-// policy_kernel.hip -- the C-METHOD greedy baseline policy, UAV.get_action_by_direction
-// (reference src/agent/uav.py:324-369), for every UAV of every environment.
+// policy_kernel.hip -- stand-alone policy kernels: (1) the C-METHOD greedy baseline policy,
+// UAV.get_action_by_direction (reference src/agent/uav.py:324-369), and (2) the learner's shared actor,
+// ActorCritic.take_action (src/models/actor_critic.py:138-148; see actor.h), for every UAV of every
+// environment.  Both also exist fused into the rollout kernel; these are the per-step forms.
 //
+// (1) greedy baseline.
 // Per UAV: score_t = 1 / d(u, t) - 0.8 * #{other UAVs (compared by position, uav.py:351) within dc
 // of t}; the first best target wins; angle = atan2(ty - y, tx - x) - heading; with probability 0.25
 // a uniformly random action instead (uav.py:338-339), with probability 0.3 the angle is zeroed
@@ -13,6 +16,7 @@
 // position when it is itself within dc.  Same geometry as the step kernel (E whole envs per workgroup,
 // one lane per UAV, poses staged in LDS).
 
+#include "actor.h"
 #include "greedy.h"
 
 namespace uavtrack {
@@ -63,7 +67,47 @@ __global__ void __launch_bounds__(kMaxWorkgroup) greedy_policy_kernel(const Gree
                                [&](int k) { return near_cnt[e * M + k]; });
 }
 
+struct ActorParams {
+    const float *obs;          // [B][N][12]
+    const float *weights;
+    const int32_t *step_count;
+    int32_t *actions;
+    float *probs;              // [B][N][A], nullable
+    int32_t B, N, A, hidden, mode;
+    int64_t env_offset;
+    uint32_t k0, k1;
+};
+
+// one lane per UAV; rows are independent, so the grid is flat over (env, uav)
+__global__ void __launch_bounds__(256) actor_policy_kernel(const ActorParams p)
+{
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (size_t)p.B * p.N) return;
+    const int b = (int)(g / p.N), i = (int)(g - (size_t)b * p.N);
+    const float4 *ip = reinterpret_cast<const float4 *>(p.obs + g * UAVTRACK_OBS_DIM);
+    const float4 q0 = ip[0], q1 = ip[1], q2 = ip[2];
+    const float o[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+    float *pr = p.probs ? p.probs + g * p.A : nullptr;
+    p.actions[g] = actor_pick<true>(o, p.weights, p.hidden, p.A, (uint64_t)(p.env_offset + b),
+                                    (uint32_t)p.step_count[b], i, p.k0, p.k1, p.mode, pr);
+}
+
 }  // namespace
+
+hipError_t launch_actor(const uavtrack_env *env, const float *obs, uint64_t seed, int mode, int32_t *actions,
+                        float *probs, hipStream_t stream)
+{
+    const uavtrack_config &c = env->cfg;
+    ActorParams p;
+    p.obs = obs; p.weights = env->actor_w; p.step_count = env->state.step_count;
+    p.actions = actions; p.probs = probs;
+    p.B = c.n_envs; p.N = c.n_uav; p.A = c.na * c.nc; p.hidden = env->actor_hidden; p.mode = mode;
+    p.env_offset = c.env_offset;
+    p.k0 = (uint32_t)seed; p.k1 = (uint32_t)(seed >> 32);
+    const size_t rows = (size_t)c.n_envs * c.n_uav;
+    hipLaunchKernelGGL(actor_policy_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
 
 hipError_t launch_greedy(const uavtrack_env *env, uint64_t seed, int32_t *actions, hipStream_t stream)
 {

@@ -34,6 +34,7 @@
 //
 // No MFMA: there is no dense contraction on this path.
 
+#include "actor.h"
 #include "greedy.h"
 
 #include <cstdlib>
@@ -345,9 +346,12 @@ __device__ __forceinline__ void sweep_weighted(const StepParams &p, int N, int M
     }
 }
 
-template <int N_, int M_, int MODE, bool Z3, bool GREEDY>
+template <int N_, int M_, int MODE, bool Z3, int POLICY>
 __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams p)
 {
+    constexpr bool GREEDY = POLICY == kPolicyGreedy;
+    constexpr bool ACTOR = POLICY == kPolicyActor;
+    constexpr bool GIVEN = POLICY == kPolicyGiven;
     extern __shared__ float4 smem4[];
     const int N = N_ > 0 ? N_ : p.N;
     const int M = M_ > 0 ? M_ : p.M;
@@ -422,7 +426,14 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         if (Z3) tzf[te * MP * 2 + k] = S.tz[gt];
     }
     int act = 0;
-    if (!GREEDY && active) act = p.actions[g];
+    if (GIVEN && active) act = p.actions[g];
+    float o[12];                                  // this UAV's local state; the actor reads last step's
+    if (ACTOR && active) {
+        const float4 *ip = reinterpret_cast<const float4 *>(p.obs_in + g * UAVTRACK_OBS_DIM);
+        const float4 q0 = ip[0], q1 = ip[1], q2 = ip[2];
+        o[0] = q0.x; o[1] = q0.y; o[2] = q0.z; o[3] = q0.w; o[4] = q1.x; o[5] = q1.y;
+        o[6] = q1.z; o[7] = q1.w; o[8] = q2.x; o[9] = q2.y; o[10] = q2.z; o[11] = q2.w;
+    }
     // Per-lane constants of the step loop: this lane's own slots in both table copies, and (when the
     // workgroup has at least one lane per target, as in every benchmark shape) its target's slot.
     float *const own0 = reinterpret_cast<float *>(uenv + (i >> 1) * 6) + (i & 1);
@@ -468,6 +479,14 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                 if (p.actions_out) p.actions_out[tg_off] = act;
             }
             __syncthreads();   // the policy has read the target table; now it may move
+        }
+
+        // ---- P0 (fused actor rollout only): take_action (actor_critic.py:138-148) on the UAV's own previous
+        //      observation, still in registers -- no table, no barrier
+        if (ACTOR && active) {
+            act = actor_pick<false>(o, p.actor_w, p.actor_hidden, p.na_total, (uint64_t)(p.env_offset + b),
+                                    (uint32_t)count, i, p.greedy_k0, p.greedy_k1, p.actor_mode, nullptr);
+            if (p.actions_out) p.actions_out[tg_off] = act;
         }
 
         // ---- P1a: targets (target.py:27-60); straight flight, mirror at the walls
@@ -524,14 +543,14 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                 float *f = own0 + pn * 12;                   // copy pn of this lane's pair row
                 f[0] = x; f[2] = y; f[4] = c; f[6] = s; f[8] = ai; f[10] = z;
             }
-            if (!GREEDY && t + 1 < p.T) act = p.actions[tg_off + BN];   // prefetch next step's action
+            if (GIVEN && t + 1 < p.T) act = p.actions[tg_off + BN];   // prefetch next step's action
             if (i == 0)
                 for (int w = 0; w < CW; ++w) covw[cbuf + e * CW + w] = 0;
         }
         __syncthreads();
 
         // ---- P2: pair sweeps
-        float o[12], tt = 0, bp = 0, dupn = 0, raw = 0;
+        float tt = 0, bp = 0, dupn = 0, raw = 0;
         const float4 *rowNew = uenv + pn * 3;
         const float4 *rowOld = uenv + (pn ^ 1) * 3;
         const v2f *tzrow = reinterpret_cast<const v2f *>(tzf + e * MP * 2);
@@ -755,35 +774,39 @@ size_t lds_bytes_for(int E, int N, int M, bool z3)
 using KernelFn = void (*)(const StepParams);
 
 template <int N_, int M_>
-KernelFn pick_mode(int mode, bool z3, bool greedy)
+KernelFn pick_mode(int mode, bool z3, int policy)
 {
-    if (greedy) {   // planar baseline policy; MAAC / MAAC-G rewards
-        return mode == UAVTRACK_REWARD_MEAN ? rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, false, true>
-                                            : rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, false, true>;
+    if (policy == kPolicyGreedy) {   // planar baseline policy; MAAC / MAAC-G rewards
+        return mode == UAVTRACK_REWARD_MEAN ? rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, false, kPolicyGreedy>
+                                            : rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, false, kPolicyGreedy>;
+    }
+    if (policy == kPolicyActor) {    // na*nc <= 12: planar; MAAC / MAAC-G rewards
+        return mode == UAVTRACK_REWARD_MEAN ? rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, false, kPolicyActor>
+                                            : rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, false, kPolicyActor>;
     }
     if (z3) {
         switch (mode) {
-        case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, true, false>;
-        case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, UAVTRACK_REWARD_PMI, true, false>;
-        default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, true, false>;
+        case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, true, kPolicyGiven>;
+        case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, UAVTRACK_REWARD_PMI, true, kPolicyGiven>;
+        default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, true, kPolicyGiven>;
         }
     }
     switch (mode) {
-    case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, false, false>;
-    case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, UAVTRACK_REWARD_PMI, false, false>;
-    default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, false, false>;
+    case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, false, kPolicyGiven>;
+    case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, UAVTRACK_REWARD_PMI, false, kPolicyGiven>;
+    default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, false, kPolicyGiven>;
     }
 }
 
-KernelFn pick_kernel(int N, int M, int mode, bool z3, int *specialised, bool greedy = false)
+KernelFn pick_kernel(int N, int M, int mode, bool z3, int *specialised, int policy = kPolicyGiven)
 {
     *specialised = 1;
-    if (N == 20 && M == 10) return pick_mode<20, 10>(mode, z3, greedy);
-    if (N == 50 && M == 25) return pick_mode<50, 25>(mode, z3, greedy);
-    if (N == 10 && M == 10) return pick_mode<10, 10>(mode, z3, greedy);
-    if (N == 5 && M == 3) return pick_mode<5, 3>(mode, z3, greedy);
+    if (N == 20 && M == 10) return pick_mode<20, 10>(mode, z3, policy);
+    if (N == 50 && M == 25) return pick_mode<50, 25>(mode, z3, policy);
+    if (N == 10 && M == 10) return pick_mode<10, 10>(mode, z3, policy);
+    if (N == 5 && M == 3) return pick_mode<5, 3>(mode, z3, policy);
     *specialised = 0;
-    return pick_mode<0, 0>(mode, z3, greedy);
+    return pick_mode<0, 0>(mode, z3, policy);
 }
 
 }  // namespace
@@ -838,10 +861,10 @@ Geometry plan_geometry(const uavtrack_config &cfg, int n_simd)
     return g;
 }
 
-hipError_t launch_rollout(const uavtrack_env *env, const StepParams &p, hipStream_t stream, bool greedy)
+hipError_t launch_rollout(const uavtrack_env *env, const StepParams &p, hipStream_t stream, int policy)
 {
     int spec = 0;
-    KernelFn fn = pick_kernel(p.N, p.M, env->cfg.reward_mode, env->cfg.dim == 3, &spec, greedy);
+    KernelFn fn = pick_kernel(p.N, p.M, env->cfg.reward_mode, env->cfg.dim == 3, &spec, policy);
     const Geometry &g = env->geo;
     hipLaunchKernelGGL(fn, dim3(g.groups), dim3(g.wgs), g.lds_bytes, stream, p);
     return hipGetLastError();

@@ -35,6 +35,8 @@ class UavtrackConfig(C.Structure):
     ]
 
 
+ACTOR_SAMPLE, ACTOR_ARGMAX = 0, 1   # enum in include/uavtrack.h
+
 # name -> (restype, argtypes); every symbol declared in include/uavtrack.h
 SIGNATURES = {
     "uavtrack_version": (C.c_int, []),
@@ -50,6 +52,9 @@ SIGNATURES = {
     "uavtrack_step_many": (C.c_int, [C.c_void_p, C.c_int32] + [C.c_void_p] * 7 + [C.c_void_p]),
     "uavtrack_run_greedy": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64] + [C.c_void_p] * 7 + [C.c_void_p]),
     "uavtrack_greedy_actions": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "uavtrack_set_actor_weights": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int32, C.c_void_p]),
+    "uavtrack_actor_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "uavtrack_run_actor": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.c_int32] + [C.c_void_p] * 8 + [C.c_void_p]),
     "uavtrack_pmi_pairs_scored": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),
     "uavtrack_kernel_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
 }

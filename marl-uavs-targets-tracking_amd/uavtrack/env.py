@@ -216,6 +216,65 @@ class BatchedUavEnv:
                                                  _ptr(ep), self._stream()), "uavtrack_run_greedy")
         return dict(actions=acts, obs=obs, reward=reward, terms=terms, covered=covered, done=done, ep_sums=ep)
 
+    # ---- the learner's shared actor on the device (actor_critic.py:85-98, 138-148) ----
+    def set_actor(self, actor) -> None:
+        """Upload FnnPolicyNet parameters: a module / state_dict with fc1.weight [H,12], fc1.bias, fc2.weight
+        [na,H], fc2.bias (actor_critic.py:85-98), or None to remove them."""
+        if actor is None:
+            _lib.check(self._lib.uavtrack_set_actor_weights(self._h, None, None, None, None, C.c_int32(0),
+                                                            self._stream()), "uavtrack_set_actor_weights")
+            return
+        sd = actor.state_dict() if hasattr(actor, "state_dict") else actor
+        host = [sd[k].detach().to("cpu", torch.float32).contiguous()
+                for k in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias")]
+        w1, b1, w2, b2 = host
+        if w1.shape[1] != _lib.OBS_DIM or w2.shape != (self.cfg.na_total, w1.shape[0]):
+            raise ValueError(f"actor shapes fc1 {tuple(w1.shape)}, fc2 {tuple(w2.shape)} do not match "
+                             f"Linear({_lib.OBS_DIM}, H) / Linear(H, {self.cfg.na_total})")
+        _lib.check(self._lib.uavtrack_set_actor_weights(self._h, *[C.c_void_p(t.data_ptr()) for t in host],
+                                                        C.c_int32(w1.shape[0]), self._stream()),
+                   "uavtrack_set_actor_weights")
+
+    def actor_actions(self, obs: torch.Tensor, seed: int = 0, mode: int = _lib.ACTOR_SAMPLE,
+                      want_probs: bool = False, out: Optional[torch.Tensor] = None):
+        """take_action for every UAV (actor_critic.py:138-148) -> int32 [B, N] (and probs [B, N, na] if asked)."""
+        if obs.shape != (self.B, self.N, _lib.OBS_DIM) or obs.dtype != torch.float32 or not obs.is_contiguous() \
+                or obs.device != self.device:
+            raise ValueError(f"obs must be a contiguous float32 [{self.B}, {self.N}, {_lib.OBS_DIM}] tensor on {self.device}")
+        a = out if out is not None else self._empty((self.B, self.N), torch.int32)
+        probs = self._empty((self.B, self.N, self.cfg.na_total), torch.float32) if want_probs else None
+        _lib.check(self._lib.uavtrack_actor_actions(self._h, _ptr(obs), C.c_uint64(seed & (2 ** 64 - 1)),
+                                                    C.c_int32(mode), _ptr(a), _ptr(probs), self._stream()),
+                   "uavtrack_actor_actions")
+        return (a, probs) if want_probs else a
+
+    def run_actor(self, T: int, obs_in: torch.Tensor, seed: int = 0, mode: int = _lib.ACTOR_SAMPLE,
+                  want_terms: bool = True, out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """T closed-loop steps of actor + environment (the rollout of train.operate_epoch, train.py:160-192) in
+        one launch.  obs_in [B, N, 12] is what the policy sees first (reset()'s return or the last obs)."""
+        if obs_in.shape != (self.B, self.N, _lib.OBS_DIM) or obs_in.dtype != torch.float32 \
+                or not obs_in.is_contiguous() or obs_in.device != self.device:
+            raise ValueError(f"obs_in must be a contiguous float32 [{self.B}, {self.N}, {_lib.OBS_DIM}] tensor on {self.device}")
+        o = out or {}
+
+        def buf(key, shape, dtype, want=True):
+            if not want:
+                return None
+            t = o.get(key)
+            return t if t is not None else self._empty(shape, dtype)
+        acts = buf("actions", (T, self.B, self.N), torch.int32)
+        obs = buf("obs", (T, self.B, self.N, _lib.OBS_DIM), torch.float32)
+        reward = buf("reward", (T, self.B, self.N), torch.float32)
+        terms = buf("terms", (T, 3, self.B, self.N), torch.float32, want_terms)
+        covered = buf("covered", (T, self.B), torch.int32)
+        done = buf("done", (T, self.B), torch.uint8)
+        ep = buf("ep_sums", (self.B, 5), torch.float32)
+        _lib.check(self._lib.uavtrack_run_actor(self._h, C.c_int32(T), C.c_uint64(seed & (2 ** 64 - 1)), C.c_int32(mode),
+                                                _ptr(obs_in), _ptr(acts), _ptr(obs), _ptr(reward), _ptr(terms),
+                                                _ptr(covered), _ptr(done), _ptr(ep), self._stream()),
+                   "uavtrack_run_actor")
+        return dict(actions=acts, obs=obs, reward=reward, terms=terms, covered=covered, done=done, ep_sums=ep)
+
     def pmi_pairs_scored(self) -> int:
         """Neighbour pairs the PMI network has scored so far (synchronises the stream)."""
         out = C.c_uint64(0)

@@ -39,11 +39,19 @@ def sample_actions(probs: torch.Tensor) -> torch.Tensor:
 
 class BatchedRollout:
     """policy = callable obs[B,N,12] -> probs[B,N,na] (e.g. ActorMLP), or the string "greedy" for the
-    reference's C-METHOD baseline (uav.py:324-369) computed by the library's own policy kernel."""
+    reference's C-METHOD baseline (uav.py:324-369) computed by the library's own policy kernel.
+
+    device_actor=True (policy must then have FnnPolicyNet's parameters, e.g. ActorMLP or the reference's own
+    actor): the policy runs inside the library -- per step as uavtrack_actor_actions, or, with `run_fused`,
+    actor and environment together in ONE launch for the whole rollout (uavtrack_run_actor); call
+    `sync_actor()` after every learner update to upload the new weights."""
 
     def __init__(self, env: BatchedUavEnv, policy, select: Callable[[torch.Tensor], torch.Tensor] = sample_actions,
-                 steps_per_graph: int = 8, use_graph: bool = True, seed: int = 0):
+                 steps_per_graph: int = 8, use_graph: bool = True, seed: int = 0, device_actor: bool = False):
         self.env, self.policy, self.select, self.seed = env, policy, select, seed
+        self.device_actor = device_actor
+        if device_actor:
+            env.set_actor(policy)
         self.k = max(1, int(steps_per_graph))
         self.use_graph = use_graph
         B = env.B
@@ -58,6 +66,8 @@ class BatchedRollout:
         if isinstance(self.policy, str):
             assert self.policy == "greedy", self.policy
             actions = self.env.greedy_actions(self.seed)     # draws are keyed by (seed, env, step_count, uav)
+        elif self.device_actor:
+            actions = self.env.actor_actions(self.obs, self.seed)
         else:
             with torch.no_grad():
                 actions = self.select(self.policy(self.obs))
@@ -103,3 +113,21 @@ class BatchedRollout:
         for _ in range(steps - done):
             self._one_step()
         return {"ep_sums": self.ep, "obs": self.obs, "reward": self.last_reward}
+
+    def sync_actor(self):
+        """Upload the policy's current parameters to the library (device_actor mode; after a learner update)."""
+        self.env.set_actor(self.policy)
+
+    def run_fused(self, steps: int, want_terms: bool = False, out: Optional[Dict[str, torch.Tensor]] = None
+                  ) -> Dict[str, torch.Tensor]:
+        """The same `steps` closed-loop steps as run(), as ONE launch (device_actor mode, MAAC / MAAC-G).  Returns
+        the launch's outputs -- obs/actions/reward [T, ...] are the transitions of train.py:176-180 (state[t] is
+        obs[t-1], or the observation held before the call for t = 0) -- plus the running episode sums."""
+        assert self.device_actor, "run_fused needs device_actor=True"
+        res = self.env.run_actor(steps, self.obs, seed=self.seed, want_terms=want_terms, out=out)
+        self.obs.copy_(res["obs"][-1])
+        self.last_reward.copy_(res["reward"][-1])
+        self.ep += res["ep_sums"]
+        res = dict(res)
+        res["ep_sums"] = self.ep
+        return res

@@ -1,2 +1,2 @@
 """CPU oracle package -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see oracle.py)."""
-from .oracle import OracleConfig, OracleEnv, OraclePmi, build, greedy_actions, lib, philox4x32_10  # noqa: F401
+from .oracle import OracleConfig, OracleEnv, OraclePmi, actor_actions, build, greedy_actions, lib, philox4x32_10  # noqa: F401

@@ -221,7 +221,29 @@ def gen_edges(pmi):
     save("g7_edges", arrays, meta)
 
 
+def gen_actor():
+    """FnnPolicyNet.forward (actor_critic.py:85-98) on recorded observations: weights + obs -> probs (fp32)."""
+    from models.actor_critic import FnnPolicyNet  # noqa: E402  (reference)
+    torch.manual_seed(7)
+    net = FnnPolicyNet(12, 128, 12)          # configs/MAAC.yaml:34 hidden_dim 128; na 12
+    with torch.no_grad():                    # default init gives a near-uniform policy; sharpen it (weights are data)
+        net.fc2.weight.mul_(6.0)
+        net.fc2.bias.uniform_(-1.0, 1.0)
+    g2 = np.load(os.path.join(OUT, "g2_n20m10_raw.npz"))
+    obs = g2["obs"].reshape(-1, 12).astype(np.float32)            # what get_local_state returned in G2
+    rng = np.random.default_rng(7)
+    obs = np.concatenate([obs, rng.normal(0.0, 2.0, size=(256, 12)).astype(np.float32)])
+    with torch.no_grad():
+        probs = net(torch.from_numpy(obs)).numpy()
+    sd = {k: v.detach().numpy().astype(np.float32) for k, v in net.state_dict().items()}
+    save("actor_h128", dict(obs=obs, probs=probs.astype(np.float32), **{k.replace(".", "__"): v for k, v in sd.items()}),
+         dict(hidden=128, na=12, torch_seed=7, source="FnnPolicyNet(12,128,12), fc2.weight x6, fc2.bias U(-1,1)"))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-actor":
+        gen_actor()
+        return
     pmi = make_pmi(128, 42)
     sd = {k: v.detach().numpy().astype(np.float32) for k, v in pmi.state_dict().items()
           if "num_batches_tracked" not in k}
@@ -234,6 +256,7 @@ def main():
     scenario("g5b_n50m25_pmi", 50, 25, 0.3, pmi, [42, 43, 44], 12)
     gen_reset()
     gen_edges(pmi)
+    gen_actor()
 
 
 if __name__ == "__main__":

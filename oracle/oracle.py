@@ -70,6 +70,7 @@ def lib():
         _lib.orc_reset_philox.restype = C.c_int
         _lib.orc_philox4x32_10.restype = None
         _lib.orc_greedy_actions.restype = C.c_int
+        _lib.orc_actor_actions.restype = C.c_int
     return _lib
 
 
@@ -236,6 +237,28 @@ def greedy_actions(env: "OracleEnv", seed: int, step_count, env_offset: int = 0)
     if rc != 0:
         raise RuntimeError(f"orc_greedy_actions failed: {rc}")
     return act, dict(score=ms, angle=ma, dist=md)
+
+
+def actor_actions(cfg: OracleConfig, obs, state_dict, seed: int, step_count, mode: int = 0, env_offset: int = 0):
+    """FnnPolicyNet.forward + take_action (actor_critic.py:85-98, 138-148) in fp64 ->
+    (actions[B,N] int32, probs[B,N,A], margin[B]).  state_dict: fc1.weight/bias, fc2.weight/bias."""
+    def g(k):
+        v = state_dict[k]
+        v = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+        return np.ascontiguousarray(v, dtype=np.float64)
+    w1, b1, w2, b2 = g("fc1.weight"), g("fc1.bias"), g("fc2.weight"), g("fc2.bias")
+    B, N, A = cfg.n_envs, cfg.n_uav, cfg.na * cfg.nc
+    assert w1.shape[1] == 12 and w2.shape == (A, w1.shape[0])
+    ob = np.ascontiguousarray(np.asarray(obs, dtype=np.float64).reshape(B, N, 12))
+    sc = np.ascontiguousarray(np.asarray(step_count, dtype=np.int32).reshape(B))
+    act = np.empty((B, N), dtype=np.int32); probs = np.empty((B, N, A)); mg = np.empty(B)
+    c = cfg.c_struct()
+    rc = lib().orc_actor_actions(C.byref(c), C.c_uint64(seed), C.c_int64(env_offset), _ip(sc), _dp(ob),
+                                 _dp(w1), _dp(b1), _dp(w2), _dp(b2), C.c_int32(w1.shape[0]), C.c_int32(mode),
+                                 _ip(act), _dp(probs), _dp(mg))
+    if rc != 0:
+        raise RuntimeError(f"orc_actor_actions failed: {rc}")
+    return act, probs, mg
 
 
 def philox4x32_10(ctr, key):

@@ -550,3 +550,69 @@ int orc_greedy_actions(const orc_config *cfg, uint64_t seed, int64_t env_offset,
     }
     return 0;
 }
+
+/* ---- the learner's shared actor: FnnPolicyNet.forward (reference src/models/actor_critic.py:85-98:
+ * Linear(12,H) - ReLU - Linear(H,A) - softmax) and ActorCritic.take_action (actor_critic.py:138-148:
+ * Categorical(probs).sample()).  torch draws from its own generator; the restated draw is the inverse
+ * CDF of the same probabilities at the Philox uniform keyed by (seed, global env, step_count, uav) --
+ * the definition include/uavtrack.h gives uavtrack_actor_actions.  mode 1 = argmax (lowest index on ties).
+ * w1 [H][12], b1 [H], w2 [A][H], b2 [A] (torch layouts, fp64).  probs [B][N][A] (nullable);
+ * margin [B] (nullable) = min over the env's UAVs of the distance from the uniform to the nearest CDF
+ * boundary (mode 0) / of the gap between the two largest probabilities (mode 1). */
+int orc_actor_actions(const orc_config *cfg, uint64_t seed, int64_t env_offset, const int32_t *step_count,
+                      const double *obs, const double *w1, const double *b1, const double *w2, const double *b2,
+                      int32_t hidden, int32_t mode, int32_t *actions, double *probs, double *margin)
+{
+    const int B = cfg->n_envs, N = cfg->n_uav, A = cfg->na * cfg->nc, H = hidden;
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    long b;
+    if (A < 1 || A > 64 || H < 1) return -1;
+    for (b = 0; b < B; ++b) {
+        const uint64_t gid = (uint64_t)(env_offset + b);
+        double mg = INFINITY;
+        int i, j, k, h;
+        for (i = 0; i < N; ++i) {
+            const double *x = obs + ((size_t)b * N + i) * 12;
+            double lg[64], pr[64], m = -INFINITY, S = 0.0;
+            for (j = 0; j < A; ++j) lg[j] = b2[j];
+            for (h = 0; h < H; ++h) {
+                double a = b1[h];
+                for (k = 0; k < 12; ++k) a += w1[(size_t)h * 12 + k] * x[k];
+                if (a < 0.0) a = 0.0;
+                for (j = 0; j < A; ++j) lg[j] += w2[(size_t)j * H + h] * a;
+            }
+            for (j = 0; j < A; ++j) if (lg[j] > m) m = lg[j];
+            for (j = 0; j < A; ++j) { pr[j] = exp(lg[j] - m); S += pr[j]; }
+            for (j = 0; j < A; ++j) {
+                pr[j] /= S;
+                if (probs) probs[((size_t)b * N + i) * A + j] = pr[j];
+            }
+            if (mode == 1) {
+                int best = 0;
+                double second = -INFINITY;
+                for (j = 1; j < A; ++j) {
+                    if (pr[j] > pr[best]) { second = pr[best]; best = j; }
+                    else if (pr[j] > second) second = pr[j];
+                }
+                if (A > 1 && pr[best] - second < mg) mg = pr[best] - second;
+                actions[(size_t)b * N + i] = best;
+            } else {
+                uint32_t ctr[4] = {(uint32_t)gid, (uint32_t)step_count[b], (uint32_t)i, 0x4143544Fu ^ (uint32_t)(gid >> 32)};
+                uint32_t r[4];
+                double u, c = 0.0;
+                int pick = A - 1;
+                orc_philox4x32_10(ctr, key, r);
+                u = (double)u01f(r[0]);
+                for (j = 0; j < A; ++j) {
+                    c += pr[j];
+                    if (j < A - 1 && fabs(c - u) < mg) mg = fabs(c - u);
+                    if (c > u) { pick = j; break; }
+                }
+                for (++j; j < A - 1; ++j) { c += pr[j]; if (fabs(c - u) < mg) mg = fabs(c - u); }
+                actions[(size_t)b * N + i] = pick;
+            }
+        }
+        if (margin) margin[b] = mg;
+    }
+    return 0;
+}

@@ -525,3 +525,86 @@ def test_greedy_baseline_policy_vs_oracle(uavtrack):
         res[mode] = ro.run(17)["ep_sums"].clone()
     assert torch.equal(res[False], res[True])
     assert res[True][:, 1].sum() > 0          # the baseline does find targets
+
+
+def golden_actor():
+    g, _ = load_golden("actor_h128")
+    sd = {k.replace("__", "."): torch.from_numpy(np.asarray(g[k])) for k in g.files if "__" in k}
+    return g, sd
+
+
+def test_device_actor_vs_reference_golden_and_oracle(uavtrack):
+    """FnnPolicyNet.forward + take_action (actor_critic.py:85-98, 138-148) on device.  Probabilities
+    within 1e-5 of the reference network's own fp32 output (golden) and of the fp64 oracle; the sampled /
+    argmax action is an index: exact wherever the oracle's margin (distance of the uniform to a CDF boundary,
+    gap between the two best probabilities) leaves fp32 no room to flip."""
+    from oracle import actor_actions
+    g, sd = golden_actor()
+    obs_all = np.asarray(g["obs"], np.float32)
+    N = 16
+    B = obs_all.shape[0] // N
+    kw = dict(n_envs=B, n_uav=N, m_targets=5)
+    env = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(env_offset=1234567890123, **kw))
+    env.reset(seed=3)
+    with pytest.raises(RuntimeError, match="uavtrack_set_actor_weights first"):
+        env.actor_actions(torch.zeros(B, N, 12, device="cuda"))
+    env.set_actor(sd)
+    obs = torch.from_numpy(obs_all[:B * N].reshape(B, N, 12)).cuda()
+    sc = env.get_state()["step_count"].cpu().numpy()
+    total = 0
+    for mode, seed in ((0, 5), (0, 2 ** 40 + 17), (1, 0)):
+        act, probs = env.actor_actions(obs, seed=seed, mode=mode, want_probs=True)
+        want_a, want_p, mg = actor_actions(OracleConfig(**kw), obs_all[:B * N], sd, seed, sc, mode=mode,
+                                           env_offset=1234567890123)
+        np.testing.assert_allclose(probs.cpu().numpy(), want_p, rtol=0, atol=ATOL)
+        np.testing.assert_allclose(probs.cpu().numpy().reshape(-1, 12), np.asarray(g["probs"])[:B * N], rtol=0, atol=ATOL)
+        ok = mg > 1e-5
+        assert ok.mean() > 0.9, ok.mean()
+        np.testing.assert_array_equal(act.cpu().numpy()[ok], want_a[ok])
+        total += int(ok.sum())
+    assert total > 2 * B
+    # the draw really follows the probabilities: one observation, many (env, uav) keys
+    B2 = 2048
+    env2 = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(n_envs=B2, n_uav=N, m_targets=5))
+    env2.reset(seed=1)
+    env2.set_actor(sd)
+    row = torch.from_numpy(obs_all[7]).cuda()
+    act, probs = env2.actor_actions(row.expand(B2, N, 12).contiguous(), seed=77, want_probs=True)
+    p = probs[0, 0].double().cpu().numpy()
+    freq = np.bincount(act.cpu().numpy().ravel(), minlength=12) / (B2 * N)
+    assert np.abs(freq - p).max() < 4.0 * np.sqrt(0.25 / (B2 * N)) + 1e-3, (freq, p)
+    assert (p > 0.02).sum() >= 3               # the golden policy is not degenerate
+
+
+@pytest.mark.parametrize("N,M,coop,mode", [(20, 10, 0.0, 0), (20, 10, 0.3, 0), (5, 3, 0.0, 1), (7, 4, 0.3, 0), (50, 25, 0.0, 0)])
+def test_fused_actor_rollout_equals_stepwise(uavtrack, N, M, coop, mode):
+    """uavtrack_run_actor (actor + environment, T steps, one launch) == T x (uavtrack_actor_actions,
+    uavtrack_step), bit for bit -- actions, observations, rewards, coverage, final state, episode sums."""
+    _, sd = golden_actor()
+    cfg = uavtrack.EnvConfig(n_envs=70, n_uav=N, m_targets=M, cooperative=coop, x_max=1100.0, y_max=900.0, env_offset=9)
+    a, b = uavtrack.BatchedUavEnv(cfg), uavtrack.BatchedUavEnv(cfg)
+    a.set_actor(sd); b.set_actor(sd)
+    obs0 = a.reset(seed=6)
+    obs = b.reset(seed=6).clone()
+    T = 19
+    fused = a.run_actor(T, obs0, seed=21, mode=mode)
+    ep = torch.zeros(cfg.n_envs, 5, device="cuda")
+    for t in range(T):
+        act = b.actor_actions(obs, seed=21, mode=mode)
+        assert torch.equal(act, fused["actions"][t]), (N, t)
+        o, rew, _ = b.step(act, ep_sums=ep)
+        obs = o.clone()
+        assert torch.equal(obs, fused["obs"][t]) and torch.equal(rew, fused["reward"][t]), (N, t)
+        assert torch.equal(b.info["covered"], fused["covered"][t])
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    np.testing.assert_allclose(fused["ep_sums"].cpu().numpy(), ep.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    assert len(torch.unique(fused["actions"])) > 3   # a policy, not a constant
+    # continuing from the last observation == one longer rollout
+    c = uavtrack.BatchedUavEnv(cfg)
+    c.set_actor(sd)
+    o0 = c.reset(seed=6)
+    first = c.run_actor(8, o0, seed=21, mode=mode)
+    second = c.run_actor(T - 8, first["obs"][-1].contiguous(), seed=21, mode=mode)
+    assert torch.equal(second["obs"][-1], fused["obs"][-1]) and torch.equal(second["actions"], fused["actions"][8:])

@@ -154,3 +154,38 @@ def test_greedy_policy_restatement_semantics():
     assert 5 in seen
     counts = [sum(int(greedy_actions(env, s, np.zeros(1, np.int32))[0][0, 0]) == v for s in range(200)) for v in (5, 11)]
     assert counts[0] > 120 and counts[1] < 30
+
+
+def test_actor_restatement_matches_reference_network():
+    """oracle.actor_actions (fp64) against probabilities recorded from the reference's own FnnPolicyNet
+    (actor_critic.py:85-98, torch fp32) -- golden actor_h128, generated by oracle/gen_golden.py."""
+    from oracle import actor_actions
+    g, _ = load_golden("actor_h128")
+    sd = {k.replace("__", "."): np.asarray(g[k]) for k in g.files if "__" in k}
+    obs = np.asarray(g["obs"], np.float64)
+    N = 16
+    B = obs.shape[0] // N
+    cfg = OracleConfig(n_envs=B, n_uav=N, m_targets=3)
+    sc = np.arange(B, dtype=np.int32)
+    act, probs, mg = actor_actions(cfg, obs[:B * N], sd, seed=11, step_count=sc)
+    np.testing.assert_allclose(probs.reshape(-1, 12), np.asarray(g["probs"])[:B * N], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(probs.sum(-1), 1.0, atol=1e-12)
+    assert act.min() >= 0 and act.max() <= 11 and np.isfinite(mg).all()
+    # take_action semantics: the draw is the inverse CDF at the Philox uniform of (seed, env, step, uav)
+    from oracle import philox4x32_10
+    for b, i in ((0, 0), (3, 5), (B - 1, N - 1)):
+        r = philox4x32_10([b, int(sc[b]), i, 0x4143544F], [11, 0])
+        u = np.float32(r[0] >> 8) * np.float32(2.0 ** -24)
+        want = int(np.searchsorted(np.cumsum(probs[b, i]), u, side="right"))
+        assert act[b, i] == min(want, 11)
+    # different keys -> different draws; argmax mode is the mode of the distribution
+    act2, _, _ = actor_actions(cfg, obs[:B * N], sd, seed=12, step_count=sc)
+    assert (act2 != act).mean() > 0.2
+    am, _, _ = actor_actions(cfg, obs[:B * N], sd, seed=11, step_count=sc, mode=1)
+    np.testing.assert_array_equal(am, probs.argmax(-1))
+    # many keys, one observation: empirical frequencies follow the probabilities
+    cfg2 = OracleConfig(n_envs=1500, n_uav=N, m_targets=3)
+    rep = np.broadcast_to(obs[7], (1500 * N, 12))
+    a3, p3, _ = actor_actions(cfg2, rep, sd, seed=5, step_count=np.zeros(1500, np.int32))
+    freq = np.bincount(a3.ravel(), minlength=12) / a3.size
+    assert np.abs(freq - p3[0, 0]).max() < 4.0 * np.sqrt(0.25 / a3.size) + 1e-3
