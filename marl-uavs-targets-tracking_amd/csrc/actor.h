@@ -1,19 +1,30 @@
 // actor.h -- the shared policy network of the reference's learner, FnnPolicyNet
 // (reference src/models/actor_critic.py:85-98: Linear(12, H) - ReLU - Linear(H, na) - softmax), and
-// ActorCritic.take_action (actor_critic.py:138-148: Categorical(probs).sample()) for one UAV, shared by
-// the stand-alone policy kernel and the fused actor rollout so that both produce the same bits.
+// ActorCritic.take_action (actor_critic.py:138-148: Categorical(probs).sample()) for the 64 UAVs of one
+// wavefront, shared by the stand-alone policy kernel and the fused actor rollout so that both produce
+// the same bits.
 //
-// One lane = one UAV: its 12-float local state sits in registers; the weights are the same for every
-// lane, so they arrive as *scalar* operands (uniform loads from the constant address space -> s_load,
-// SGPR pairs feeding v_pk_fma_f32) and cost no vector register, LDS or vector-memory traffic.  Per
-// hidden unit: 6 packed FMAs for the 12 inputs, a horizontal add + bias + ReLU, 6 packed FMAs into the
-// 12 logits; H = 128 (configs/MAAC.yaml:34) is ~1.8 k VALU per UAV-step.
+// One lane = one UAV, but the two Linear layers are GEMM-shaped (64 samples x 12 x H and 64 x H x 16
+// per wavefront-step) and every lane needs every weight, so they run on the matrix cores, transposed:
+//     Ht [H x 64]  = relu(W1 [H x 12] . Xt [12 x 64] + b1)        3 k-steps of v_mfma_f32_16x16x4_f32
+//     Lt [16 x 64] = W2 [16 x H] . Ht [H x 64] + b2               H/4 k-steps
+// In the transposed form the weights are the A operand (streamed from L1/L2 as ready-made fragments,
+// one coalesced 256-B load per fragment), the samples are the B/N side, and -- the point of the layout --
+// the accumulator fragment of the first GEMM *is* the B fragment of the second: D[i = 4*(l/16) + v][j =
+// l%16] in register v of lane l is B[k = l/16][j = l%16] for the k-step made of hidden units
+// {v, 4 + v, 8 + v, 12 + v} of the 16-unit block, so the hidden layer never leaves its registers (the
+// k-order of a sum is free; W2's fragments are packed in that order).  Only the 12 inputs and the 16
+// logits of a sample cross lanes, through 5 KB of LDS private to the wavefront.
+// fp32 MFMA throughout (fp32 parity with the torch actor, 1e-5 on the probabilities); measured against
+// a first version that fed v_pk_fma_f32 from scalar loads (weights as SGPR operands), which was bound
+// by scalar-cache bandwidth: 15.6 -> see DESIGN.md for the closed-loop numbers.
 //
-// Device weight blob (uavtrack_set_actor_weights packs it): kActorRow = 26 floats per hidden unit h --
-// W1[h][0..11], b1[h], pad, W2[0..11][h] -- followed by one row holding b2[0..11].  Rows are packed
-// tightly on purpose: at H = 128 the blob is 13.4 KB and stays resident in the 16 KB scalar cache that
-// every wave of the CU streams it through.
-// Action slots >= na*nc are zero-padded and masked out of the softmax.
+// Device weight blob (uavtrack_set_actor_weights packs it), in units of one fragment = 64 floats, lane
+// l at offset l; HB = ceil(H/16) blocks of 11 fragments, then 4 fragments of b2:
+//   block a:  W1 s=0..2 : W1[16a + l%16][4s + l/16]
+//             b1 v=0..3 : b1[16a + 4*(l/16) + v]
+//             W2 v=0..3 : W2[l%16][16a + 4*(l/16) + v]          (rows >= na*nc and units >= H are zero)
+//   tail:     b2 v=0..3 : b2[4*(l/16) + v]
 //
 // Sampling: torch's Categorical draws from torch's own generator, which has no place inside a kernel;
 // here the draw is the inverse CDF of the same probabilities at a Philox uniform keyed by
@@ -24,65 +35,129 @@
 
 namespace uavtrack {
 
-#ifndef UAVTRACK_ACTOR_ROW
-#define UAVTRACK_ACTOR_ROW 26
-#endif
-constexpr int kActorRow = UAVTRACK_ACTOR_ROW;          // floats per hidden unit (even: rows are read as float2)
-constexpr int kActorW2 = kActorRow >= 32 ? 16 : 14;    // offset of the W2 column inside a row
-constexpr int kActorMaxActions = 12;
-constexpr int kActorObs = UAVTRACK_OBS_DIM;   // 12
+constexpr int kActorMaxActions = 16;
+constexpr int kActorObs = UAVTRACK_OBS_DIM;            // 12
+constexpr int kActorFragsPerBlock = 11;
+constexpr int kActorLdsFloats = 64 * 20;               // per wavefront: logits at a 20-float stride (conflict-free b128)
 
-typedef float actor_v2 __attribute__((ext_vector_type(2)));
-typedef const actor_v2 __attribute__((address_space(4))) *actor_cptr;   // constant address space: scalar loads
+typedef float actor_v4 __attribute__((ext_vector_type(4)));
 
-inline size_t actor_blob_floats(int hidden) { return (size_t)(hidden + 1) * kActorRow; }
+inline int actor_blocks(int hidden) { return (hidden + 15) / 16; }
+inline size_t actor_blob_floats(int hidden) { return ((size_t)actor_blocks(hidden) * kActorFragsPerBlock + 4) * 64; }
 
-// mode: UAVTRACK_ACTOR_SAMPLE (inverse-CDF draw) or UAVTRACK_ACTOR_ARGMAX (lowest index on ties)
-template <bool WANT_PROBS>
-__device__ __forceinline__ int actor_pick(const float (&o)[kActorObs], const float *weights, int H, int A,
-                                          uint64_t genv, uint32_t step, int i, uint32_t k0, uint32_t k1, int mode,
-                                          float *probs)
+// Host side: torch layouts (w1 [H][12], b1 [H], w2 [A][H], b2 [A]) -> fragment order above.
+inline void pack_actor_blob(const float *w1, const float *b1, const float *w2, const float *b2, int H, int A, float *blob)
 {
-    const actor_cptr w = (actor_cptr)(uintptr_t)weights;
-    actor_v2 x[6], l[6];
+    const int HB = actor_blocks(H);
+    for (int a = 0; a < HB; ++a) {
+        float *blk = blob + (size_t)a * kActorFragsPerBlock * 64;
+        for (int l = 0; l < 64; ++l) {
+            const int j = l & 15, g = l >> 4;
+            for (int s = 0; s < 3; ++s) {
+                const int u = 16 * a + j;
+                blk[s * 64 + l] = u < H ? w1[(size_t)u * kActorObs + 4 * s + g] : 0.0f;
+            }
+            for (int v = 0; v < 4; ++v) {
+                const int u = 16 * a + 4 * g + v;
+                blk[(3 + v) * 64 + l] = u < H ? b1[u] : 0.0f;
+                blk[(7 + v) * 64 + l] = (u < H && j < A) ? w2[(size_t)j * H + u] : 0.0f;
+            }
+        }
+    }
+    float *tail = blob + (size_t)HB * kActorFragsPerBlock * 64;
+    for (int l = 0; l < 64; ++l)
+        for (int v = 0; v < 4; ++v) {
+            const int act = 4 * (l >> 4) + v;
+            tail[v * 64 + l] = act < A ? b2[act] : 0.0f;
+        }
+}
+
+// EVERY lane of the wavefront must reach this call together (MFMA ignores EXEC); lanes without a UAV pass
+// zeros and ignore the result.  lds: kActorLdsFloats floats private to this wavefront.
+// mode: UAVTRACK_ACTOR_SAMPLE (inverse-CDF draw) or UAVTRACK_ACTOR_ARGMAX (lowest index on ties).
+template <bool WANT_PROBS>
+__device__ __forceinline__ int actor_pick(const float (&o)[kActorObs], float *lds, const float *__restrict__ weights,
+                                          int HB, int A, uint64_t genv, uint32_t step, int i, uint32_t k0, uint32_t k1,
+                                          int mode, float *probs)
+{
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    // ---- the 12 inputs of the 64 samples, regrouped into B fragments: lane l <- obs[16n + l%16][4s + l/16]
+    {
+        float4 *xs = reinterpret_cast<float4 *>(lds + lane * kActorObs);
+        xs[0] = make_float4(o[0], o[1], o[2], o[3]);
+        xs[1] = make_float4(o[4], o[5], o[6], o[7]);
+        xs[2] = make_float4(o[8], o[9], o[10], o[11]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float xf[4][3];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        x[k] = (actor_v2){o[2 * k], o[2 * k + 1]};
-        l[k] = (actor_v2){0.0f, 0.0f};
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) xf[n][s] = lds[(16 * n + j) * kActorObs + 4 * s + g];
+
+    const float *wl = weights + lane;
+    actor_v4 d2[4];
+    {
+        const float *t = wl + (size_t)HB * kActorFragsPerBlock * 64;
+        const actor_v4 b2f = {t[0], t[64], t[128], t[192]};
+#pragma unroll
+        for (int n = 0; n < 4; ++n) d2[n] = b2f;
     }
 #pragma unroll 2
-    for (int h = 0; h < H; ++h) {
-        const actor_cptr row = w + h * (kActorRow / 2);
-        actor_v2 acc = row[0] * x[0];
+    for (int a = 0; a < HB; ++a) {
+        const float *wa = wl + (size_t)a * kActorFragsPerBlock * 64;
+        float wf[kActorFragsPerBlock];
 #pragma unroll
-        for (int k = 1; k < 6; ++k) acc = __builtin_elementwise_fma(row[k], x[k], acc);
-        const float a = fmaxf(acc.x + acc.y + row[6].x, 0.0f);
-        const actor_v2 a2 = {a, a};
+        for (int f = 0; f < kActorFragsPerBlock; ++f) wf[f] = wa[f * 64];
+        const actor_v4 b1f = {wf[3], wf[4], wf[5], wf[6]};
+        actor_v4 d1[4];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) l[j] = __builtin_elementwise_fma(row[kActorW2 / 2 + j], a2, l[j]);
+        for (int n = 0; n < 4; ++n) d1[n] = b1f;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) d1[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xf[n][s], d1[n], 0, 0, 0);
+        // ReLU as one v_med3_f32 per element (fmaxf on an MFMA result costs a canonicalising v_max first)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) d1[n][v] = __builtin_amdgcn_fmed3f(d1[n][v], 0.0f, 3.0e38f);
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) d2[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[7 + v], d1[n][v], d2[n], 0, 0, 0);
     }
-    const actor_cptr b2 = w + H * (kActorRow / 2);
+    // ---- logits back to their own lane: lane l holds actions 4*(l/16) .. +3 of samples 16n + l%16
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+        *reinterpret_cast<float4 *>(lds + (16 * n + j) * 20 + 4 * g) = make_float4(d2[n][0], d2[n][1], d2[n][2], d2[n][3]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     float lg[kActorMaxActions];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const actor_v2 v = l[j] + b2[j];
-        lg[2 * j] = (2 * j < A) ? v.x : -INFINITY;
-        lg[2 * j + 1] = (2 * j + 1 < A) ? v.y : -INFINITY;
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4 *>(lds + lane * 20 + 4 * q);
+        lg[4 * q] = v.x; lg[4 * q + 1] = v.y; lg[4 * q + 2] = v.z; lg[4 * q + 3] = v.w;
     }
+    __builtin_amdgcn_wave_barrier();                 // the next call's input staging must not overtake these reads
+#pragma unroll
+    for (int q = 0; q < kActorMaxActions; ++q) lg[q] = (q < A) ? lg[q] : -INFINITY;
     float m = lg[0];
     int am = 0;
 #pragma unroll
-    for (int j = 1; j < kActorMaxActions; ++j)
-        if (lg[j] > m) { m = lg[j]; am = j; }
+    for (int q = 1; q < kActorMaxActions; ++q)
+        if (lg[q] > m) { m = lg[q]; am = q; }
     float ex[kActorMaxActions], S = 0.0f;
 #pragma unroll
-    for (int j = 0; j < kActorMaxActions; ++j) {
-        ex[j] = __builtin_amdgcn_exp2f((lg[j] - m) * 1.44269504088896340736f);   // masked slots: exp2(-inf) = 0
-        S += ex[j];
+    for (int q = 0; q < kActorMaxActions; ++q) {
+        ex[q] = __builtin_amdgcn_exp2f((lg[q] - m) * 1.44269504088896340736f);   // masked slots: exp2(-inf) = 0
+        S += ex[q];
     }
     if (WANT_PROBS && probs) {
         const float inv = 1.0f / S;
-        for (int j = 0; j < A; ++j) probs[j] = ex[j] * inv;
+        for (int q = 0; q < A; ++q) probs[q] = ex[q] * inv;
     }
     if (mode == UAVTRACK_ACTOR_ARGMAX) return am;
     const Philox4 r = philox4x32_10((uint32_t)genv, step, (uint32_t)i, 0x4143544Fu ^ (uint32_t)(genv >> 32), k0, k1);
@@ -91,9 +166,9 @@ __device__ __forceinline__ int actor_pick(const float (&o)[kActorObs], const flo
     int pick = A - 1;                       // rounding can leave the last cumulative sum <= target
     bool found = false;
 #pragma unroll
-    for (int j = 0; j < kActorMaxActions; ++j) {
-        c += ex[j];
-        if (!found && c > target && j < A) { pick = j; found = true; }
+    for (int q = 0; q < kActorMaxActions; ++q) {
+        c += ex[q];
+        if (!found && c > target && q < A) { pick = q; found = true; }
     }
     return pick;
 }

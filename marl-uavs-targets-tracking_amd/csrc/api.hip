@@ -460,19 +460,13 @@ int uavtrack_set_actor_weights(uavtrack_env *env, const float *w1, const float *
     }
     if (!b1 || !w2 || !b2) return fail("uavtrack_set_actor_weights: b1, w2 and b2 must not be null");
     const int A = env->cfg.na * env->cfg.nc;
-    if (A > kActorMaxActions)
+    if (A > 12)
         return fail("uavtrack_set_actor_weights: na*nc = %d actions; the device actor is built for the reference's "
-                    "action space (<= %d)", A, kActorMaxActions);
+                    "action space (<= %d)", A, 12);
     if (hidden < 1 || hidden > 4096) return fail("uavtrack_set_actor_weights: hidden %d out of range [1, 4096]", hidden);
     const size_t n = actor_blob_floats(hidden);
     std::vector<float> blob(n, 0.0f);
-    for (int h = 0; h < hidden; ++h) {
-        float *row = blob.data() + (size_t)h * kActorRow;
-        for (int k = 0; k < UAVTRACK_OBS_DIM; ++k) row[k] = w1[(size_t)h * UAVTRACK_OBS_DIM + k];
-        row[12] = b1[h];
-        for (int j = 0; j < A; ++j) row[kActorW2 + j] = w2[(size_t)j * hidden + h];
-    }
-    for (int j = 0; j < A; ++j) blob[(size_t)hidden * kActorRow + j] = b2[j];
+    pack_actor_blob(w1, b1, w2, b2, hidden, A, blob.data());
     if (env->actor_hidden != hidden) {
         if (env->actor_w) (void)hipFree(env->actor_w);
         env->actor_w = nullptr; env->actor_hidden = 0;
@@ -523,7 +517,7 @@ int uavtrack_run_actor(uavtrack_env *env, int32_t T, uint64_t seed, int32_t mode
     p.pairs = nullptr; p.pair_count = nullptr; p.ep_accumulate = 0;
     p.env_offset = env->cfg.env_offset;
     p.greedy_k0 = (uint32_t)seed; p.greedy_k1 = (uint32_t)(seed >> 32);
-    p.obs_in = obs_in; p.actor_w = env->actor_w; p.actor_hidden = env->actor_hidden; p.actor_mode = mode;
+    p.obs_in = obs_in; p.actor_w = env->actor_w; p.actor_hblocks = actor_blocks(env->actor_hidden); p.actor_mode = mode;
     HIP_TRY(launch_rollout(env, p, static_cast<hipStream_t>(stream), kPolicyActor));
     return 0;
 }

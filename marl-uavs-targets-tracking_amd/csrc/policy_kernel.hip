@@ -73,23 +73,32 @@ struct ActorParams {
     const int32_t *step_count;
     int32_t *actions;
     float *probs;              // [B][N][A], nullable
-    int32_t B, N, A, hidden, mode;
+    int32_t B, N, A, hblocks, mode;
     int64_t env_offset;
     uint32_t k0, k1;
 };
 
-// one lane per UAV; rows are independent, so the grid is flat over (env, uav)
+// one lane per UAV, 64 UAVs per wavefront (the MFMA tile), flat over (env, uav); whole wavefronts stay
+// in step through actor_pick, lanes past the end carry zeros
 __global__ void __launch_bounds__(256) actor_policy_kernel(const ActorParams p)
 {
+    __shared__ float lds[4][kActorLdsFloats];
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= (size_t)p.B * p.N) return;
-    const int b = (int)(g / p.N), i = (int)(g - (size_t)b * p.N);
-    const float4 *ip = reinterpret_cast<const float4 *>(p.obs + g * UAVTRACK_OBS_DIM);
-    const float4 q0 = ip[0], q1 = ip[1], q2 = ip[2];
-    const float o[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
-    float *pr = p.probs ? p.probs + g * p.A : nullptr;
-    p.actions[g] = actor_pick<true>(o, p.weights, p.hidden, p.A, (uint64_t)(p.env_offset + b),
-                                    (uint32_t)p.step_count[b], i, p.k0, p.k1, p.mode, pr);
+    const bool valid = g < (size_t)p.B * p.N;
+    float o[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int b = 0, i = 0, step = 0;
+    if (valid) {
+        b = (int)(g / p.N); i = (int)(g - (size_t)b * p.N);
+        const float4 *ip = reinterpret_cast<const float4 *>(p.obs + g * UAVTRACK_OBS_DIM);
+        const float4 q0 = ip[0], q1 = ip[1], q2 = ip[2];
+        o[0] = q0.x; o[1] = q0.y; o[2] = q0.z; o[3] = q0.w; o[4] = q1.x; o[5] = q1.y;
+        o[6] = q1.z; o[7] = q1.w; o[8] = q2.x; o[9] = q2.y; o[10] = q2.z; o[11] = q2.w;
+        step = p.step_count[b];
+    }
+    float *pr = (valid && p.probs) ? p.probs + g * p.A : nullptr;
+    const int act = actor_pick<true>(o, lds[threadIdx.x >> 6], p.weights, p.hblocks, p.A, (uint64_t)(p.env_offset + b),
+                                     (uint32_t)step, i, p.k0, p.k1, p.mode, pr);
+    if (valid) p.actions[g] = act;
 }
 
 }  // namespace
@@ -101,7 +110,7 @@ hipError_t launch_actor(const uavtrack_env *env, const float *obs, uint64_t seed
     ActorParams p;
     p.obs = obs; p.weights = env->actor_w; p.step_count = env->state.step_count;
     p.actions = actions; p.probs = probs;
-    p.B = c.n_envs; p.N = c.n_uav; p.A = c.na * c.nc; p.hidden = env->actor_hidden; p.mode = mode;
+    p.B = c.n_envs; p.N = c.n_uav; p.A = c.na * c.nc; p.hblocks = actor_blocks(env->actor_hidden); p.mode = mode;
     p.env_offset = c.env_offset;
     p.k0 = (uint32_t)seed; p.k1 = (uint32_t)(seed >> 32);
     const size_t rows = (size_t)c.n_envs * c.n_uav;

@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     }
     int act = 0;
     if (GIVEN && active) act = p.actions[g];
-    float o[12];                                  // this UAV's local state; the actor reads last step's
+    float o[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // this UAV's local state; the actor reads last step's
     if (ACTOR && active) {
         const float4 *ip = reinterpret_cast<const float4 *>(p.obs_in + g * UAVTRACK_OBS_DIM);
         const float4 q0 = ip[0], q1 = ip[1], q2 = ip[2];
@@ -483,10 +483,11 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
 
         // ---- P0 (fused actor rollout only): take_action (actor_critic.py:138-148) on the UAV's own previous
         //      observation, still in registers -- no table, no barrier
-        if (ACTOR && active) {
-            act = actor_pick<false>(o, p.actor_w, p.actor_hidden, p.na_total, (uint64_t)(p.env_offset + b),
+        if (ACTOR) {     // whole wavefronts: the two layers run on the matrix cores (actor.h)
+            float *alds = reinterpret_cast<float *>(reinterpret_cast<char *>(smem4) + p.actor_lds_off) + (tid >> 6) * kActorLdsFloats;
+            act = actor_pick<false>(o, alds, p.actor_w, p.actor_hblocks, p.na_total, (uint64_t)(p.env_offset + b),
                                     (uint32_t)count, i, p.greedy_k0, p.greedy_k1, p.actor_mode, nullptr);
-            if (p.actions_out) p.actions_out[tg_off] = act;
+            if (active && p.actions_out) p.actions_out[tg_off] = act;
         }
 
         // ---- P1a: targets (target.py:27-60); straight flight, mirror at the walls
@@ -866,7 +867,13 @@ hipError_t launch_rollout(const uavtrack_env *env, const StepParams &p, hipStrea
     int spec = 0;
     KernelFn fn = pick_kernel(p.N, p.M, env->cfg.reward_mode, env->cfg.dim == 3, &spec, policy);
     const Geometry &g = env->geo;
-    hipLaunchKernelGGL(fn, dim3(g.groups), dim3(g.wgs), g.lds_bytes, stream, p);
+    size_t lds = g.lds_bytes;
+    StepParams q = p;
+    if (policy == kPolicyActor) {
+        q.actor_lds_off = (int32_t)lds;
+        lds += (size_t)(g.wgs / 64) * kActorLdsFloats * sizeof(float);
+    }
+    hipLaunchKernelGGL(fn, dim3(g.groups), dim3(g.wgs), lds, stream, q);
     return hipGetLastError();
 }
 
