@@ -150,3 +150,84 @@ def test_export_matches_reference_csv_layout(tmp_path):
     cov = np.arange(T * B).reshape(T, B)
     cpath = save_covered_num(str(tmp_path), 5, cov, env_index=2)
     np.testing.assert_array_equal(np.loadtxt(cpath, skiprows=1), cov[:, 2])
+
+
+def test_replay_buffers_reference_semantics():
+    """DeviceReplayBuffer / PrioritizedDeviceReplayBuffer against the semantics of train.py:41-139 (deque(maxlen)
+    FIFO, sampling without / with replacement, max-priority insertion, importance weights), on CPU tensors."""
+    import collections
+    import torch
+    from uavtrack import DeviceReplayBuffer, PrioritizedDeviceReplayBuffer, transitions_from_rollout
+    g = torch.Generator().manual_seed(0)
+    T, B, N = 5, 3, 4
+    obs_in = torch.randn(B, N, 12, generator=g)
+    out = {"obs": torch.randn(T, B, N, 12, generator=g), "actions": torch.randint(0, 12, (T, B, N), generator=g).int(),
+           "reward": torch.randn(T, B, N, generator=g)}
+    tr = transitions_from_rollout(obs_in, out)
+    n = T * B * N
+    assert tr["states"].shape == (n, 12) and torch.equal(tr["states"][:B * N], obs_in.reshape(-1, 12))
+    assert torch.equal(tr["states"][B * N:], out["obs"][:-1].reshape(-1, 12)) and torch.equal(tr["next_states"], out["obs"].reshape(-1, 12))
+    # FIFO overwrite == deque(maxlen)
+    cap = 37
+    buf = DeviceReplayBuffer(cap, "cpu")
+    ref = collections.deque(maxlen=cap)
+    for rep in range(3):
+        buf.add(tr)
+        ref.extend(zip(tr["states"], tr["actions"], tr["rewards"], tr["next_states"]))
+        assert buf.size() == len(ref)
+    order = [(buf.pos + k) % cap for k in range(cap)]            # oldest -> newest
+    for slot, (s, a, r, s2) in zip(order, ref):
+        assert torch.equal(buf.store["states"][slot], s) and buf.store["actions"][slot] == a
+        assert buf.store["rewards"][slot] == r and torch.equal(buf.store["next_states"][slot], s2)
+    smp = buf.sample(20, generator=g)
+    assert smp["states"].shape == (20, 12) and smp["actions"].dtype == torch.int32
+    rows = {tuple(x.tolist()) for x in buf.store["states"]}
+    assert all(tuple(x.tolist()) in rows for x in smp["states"])
+    assert len({tuple(x.tolist()) for x in smp["states"]}) == 20      # without replacement
+    assert buf.sample(1000)["actions"].numel() == cap                 # min(batch, size)
+    # one add larger than the capacity keeps the newest `capacity` transitions
+    big = DeviceReplayBuffer(10, "cpu")
+    big.add(tr)
+    assert big.size() == 10
+    newest = {tuple(x.tolist()) for x in tr["states"][-10:]}
+    assert {tuple(x.tolist()) for x in big.store["states"]} == newest
+    # prioritised
+    pb = PrioritizedDeviceReplayBuffer(64, "cpu", alpha=0.6)
+    assert pb.sample(4)[1] is None
+    pb.add({k: v[:16] for k, v in tr.items()})
+    assert torch.all(pb.priorities[:16] == 1.0) and torch.all(pb.priorities[16:] == 0.0)
+    pb.update_priorities(torch.tensor([3, 5]), torch.tensor([9.0, 0.25]))
+    pb.add({k: v[16:20] for k, v in tr.items()})
+    assert torch.all(pb.priorities[16:20] == 9.0)                     # new entries take the current maximum
+    smp, idx, w = pb.sample(4000, beta=0.4, generator=g)
+    assert idx.numel() == 20 and w.max() == 1.0                      # min(batch, size), with replacement
+    smp, idx, w = PrioritizedDeviceReplayBuffer.sample(pb, 20, 0.4, g)
+    prob = pb.priorities[:20] ** 0.6
+    prob = prob / prob.sum()
+    want_w = (20 * prob[idx]) ** -0.4
+    np.testing.assert_allclose(w.numpy(), (want_w / want_w.max()).numpy(), rtol=1e-6)
+    many = torch.multinomial(prob, 20000, replacement=True, generator=g)
+    freq = torch.bincount(many, minlength=20).double() / 20000
+    assert abs(freq[3] - prob[3].double()) < 0.01 and freq[3] > 3 * freq[0]
+
+
+def test_pmi_training_data_path():
+    """sample_pmi_pairs == the per-row copy loop of PMINet.py:78-84 for the same indices; loss == CustomLoss."""
+    import torch
+    from uavtrack import sample_pmi_pairs, pmi_contrastive_loss, pmi_batches
+    g = torch.Generator().manual_seed(1)
+    T, N = 11, 6
+    data = torch.randn(T * N, 12, generator=g)
+    sel, t_idx, u_idx = sample_pmi_pairs(data, N, 50, generator=g)
+    assert sel.shape == (50, 2, 12) and t_idx.max() < T and u_idx.max() < N
+    view = data.view(T, N, 12)
+    want = torch.zeros(50, 2, 12)
+    for i in range(50):                                   # the reference's loop
+        want[i] = view[t_idx[i], u_idx[i]]
+    assert torch.equal(sel, want)
+    o1, o2 = torch.randn(32, 1, generator=g) * 3, torch.randn(32, 1, generator=g) * 3
+    ref_loss = torch.mean(torch.log(1 + torch.exp(-o1)) + torch.log(1 + torch.exp(o2)))
+    assert torch.allclose(pmi_contrastive_loss(o1, o2), ref_loss, rtol=1e-6)
+    assert torch.isfinite(pmi_contrastive_loss(torch.tensor([-200.0]), torch.tensor([200.0])))   # the naive form overflows
+    batches = list(pmi_batches(sel, 16))
+    assert len(batches) == 3 and batches[0][0].shape == (16, 12) and torch.equal(batches[1][1], sel[16:32, 1])
