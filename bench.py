@@ -55,6 +55,10 @@ def parse():
                     help="raw = MAAC (configs[1]), mean = MAAC-G, pmi = MAAC-R (configs[2])")
     ap.add_argument("--pmi-hidden", type=int, default=128)
     ap.add_argument("--rollout", type=int, default=200, help="steps per fused launch (1 = one launch per step)")
+    ap.add_argument("--policy", choices=["given", "greedy", "actor"], default="given",
+                    help="where actions come from: pre-sampled (the headline workload), the fused greedy baseline "
+                         "(uavtrack_run_greedy) or the fused FnnPolicyNet actor (uavtrack_run_actor, hidden --actor-hidden)")
+    ap.add_argument("--actor-hidden", type=int, default=128)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip per-step-launch and saturating-batch legs")
@@ -94,6 +98,10 @@ def make_env(uavtrack, args, B, device, env_offset=0):
     env = uavtrack.BatchedUavEnv(cfg, device)
     if args.reward == "pmi":
         env.set_pmi(synthetic_pmi_state_dict(args.pmi_hidden, 42))
+    if getattr(args, "policy", "given") == "actor":
+        import torch
+        torch.manual_seed(args.seed)
+        env.set_actor(uavtrack.ActorMLP(hidden_dim=args.actor_hidden, action_dim=env.cfg.na_total))
     return env
 
 
@@ -109,15 +117,22 @@ def launch_plan(steps, rollout, horizon, ep_steps):
     return plan, ep_steps
 
 
-def run_rollouts(env, actions, plan, ep_steps, out, events=None, gather=None):
-    """Issue the launches of `plan`; gathers the episode summaries and resets at every episode end."""
+def run_rollouts(env, actions, plan, ep_steps, out, events=None, gather=None, policy="given", obs=None):
+    """Issue the launches of `plan`; gathers the episode summaries and resets at every episode end.
+    obs: the observation the in-kernel policy sees first (policy != "given")."""
     import torch
     horizon = env.cfg.horizon
     for T in plan:
         if events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        res = env.step_many(actions[ep_steps:ep_steps + T], out=out.get(T))   # the episode's own action rows
+        if policy == "actor":
+            res = env.run_actor(T, obs, seed=42, out=out.get(T))
+            obs = res["obs"][-1]
+        elif policy == "greedy":
+            res = env.run_greedy(T, seed=42)
+        else:
+            res = env.step_many(actions[ep_steps:ep_steps + T], out=out.get(T))   # the episode's own action rows
         if events is not None:
             e1.record()
             events.append((e0, e1, T))
@@ -126,9 +141,9 @@ def run_rollouts(env, actions, plan, ep_steps, out, events=None, gather=None):
         if ep_steps >= horizon:               # end of an episode: gather summaries, start the next one
             if gather is not None:
                 gather(res["ep_sums"])
-            env.reset(seed=42)
+            obs = env.reset(seed=42)
             ep_steps = 0
-    return len(plan)
+    return len(plan), obs
 
 
 def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, env_offset=0, total_envs=None):
@@ -155,15 +170,17 @@ def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, en
                       covered=torch.empty(T, B, dtype=torch.int32, device=device),
                       done=torch.empty(T, B, dtype=torch.uint8, device=device),
                       ep_sums=torch.empty(B, 5, device=device))
-    env.reset(seed=args.seed)
-    run_rollouts(env, actions, warm_plan, 0, out, gather=gather)
+        if args.policy == "actor":
+            out[T]["actions"] = torch.empty(T, B, args.n_uav, dtype=torch.int32, device=device)
+    obs0 = env.reset(seed=args.seed)
+    _, obs0 = run_rollouts(env, actions, warm_plan, 0, out, gather=gather, policy=args.policy, obs=obs0)
     torch.cuda.synchronize(device)
     if gather is not None:
         dist.barrier()
     events = []
     pairs0 = env.pmi_pairs_scored() if args.reward == "pmi" else 0
     t0 = time.perf_counter()
-    launches = run_rollouts(env, actions, timed_plan, pos, out, events=events, gather=gather)
+    launches, _ = run_rollouts(env, actions, timed_plan, pos, out, events=events, gather=gather, policy=args.policy, obs=obs0)
     torch.cuda.synchronize(device)
     if gather is not None:
         dist.barrier()
@@ -284,11 +301,14 @@ def main():
                                "pmi": f"MAAC-R reciprocal (PMI H={args.pmi_hidden}) reward"}[args.reward]
                             + (f" (BASELINE configs[{4 if world > 1 else (3 if args.dim == 3 else {'raw': 1, 'mean': 1, 'pmi': 2}[args.reward])}])"),
                 "envs_total": world * B,
-                "launch": (f"uavtrack_step_many, {args.rollout} steps per call, reset between rollouts"
+                "launch": (f"{ {'given': 'uavtrack_step_many', 'greedy': 'uavtrack_run_greedy', 'actor': 'uavtrack_run_actor'}[args.policy] }, {args.rollout} steps per call, reset between rollouts"
                            + ("; MAAC-R issues 3 kernels per step (fused step, MFMA pair scorer, softmax mix)"
                               if args.reward == "pmi" else " (one kernel launch per call)"))
                           if args.rollout > 1 else "uavtrack_step, one launch per step",
-                "actions": "pre-sampled int32[T,B,N] uniform, seed 42, resident in HBM",
+                "actions": {"given": "pre-sampled int32[T,B,N] uniform, seed 42, resident in HBM",
+                            "greedy": "in-kernel C-METHOD baseline policy (uavtrack_run_greedy), closed loop",
+                            "actor": f"in-kernel FnnPolicyNet 12-{args.actor_hidden}-{12 * (3 if args.dim == 3 else 1)} actor, random init, "
+                                     "Categorical sample (uavtrack_run_actor), closed loop"}[args.policy],
                 "outputs": "obs[T,B,N,12] reward[T,B,N] terms[T,3,B,N] covered[T,B] done[T,B] ep_sums[B,5], all written",
                 "parallelism": (f"env-sharded x{world}, {'RCCL' if args.backend == 'nccl' else args.backend} "
                                 f"all-gather of ep_sums per rollout") if world > 1 else "1 GPU",
@@ -334,7 +354,14 @@ def main():
                     line["roofline"]["traffic_source"] = tr[key].get("source", "profiles/")
             except Exception:
                 pass
-        if world == 1 and not args.no_extras and args.reward != "pmi":
+        if args.policy == "actor":
+            # the actor adds 2*(12*H + H*16) fp32 MFMA flops per agent-step (actions padded to a 16-row tile)
+            Hp = (args.actor_hidden + 15) // 16 * 16
+            line["roofline"]["actor_mfma_flop_per_agent_step"] = 2 * (12 * Hp + Hp * 16)
+            line["roofline"]["actor_mfma_tflops"] = line["roofline"]["actor_mfma_flop_per_agent_step"] * avg_units / (avg_launch_ms * 1e-3) / 1e12
+            line["roofline"]["note"] = ("closed-loop launch: environment step (HBM roofline above) plus the policy network on the "
+                                        "fp32 matrix cores (peak 157.3 TFLOP/s); both figures are over the whole launch")
+        if world == 1 and not args.no_extras and args.reward != "pmi" and args.policy == "given":
             # the same kernel, one launch per env step (what a closed-loop policy would do eagerly)
             k = min(args.steps, 1000)
             r1 = time_config(uavtrack, args, B, k, min(args.warmup, 200), 1, device)
@@ -353,7 +380,7 @@ def main():
                 "roofline_achieved_GBs": ach, "roofline_frac": ach / HBM_PEAK_GBS,
                 "avg_launch_ms": rs["kernel_ms_total"] / rs["launches"], "geometry": rs["geometry"],
             }
-        if world == 1 and not args.no_extras and args.reward != "pmi":
+        if world == 1 and not args.no_extras and args.reward != "pmi" and args.policy == "given":
             # closed loop: actor forward [B*N,12] -> sample -> uavtrack_step per step, eager
             # launches vs the same steps replayed from a HIP graph
             torch.manual_seed(args.seed)

@@ -186,7 +186,9 @@ int uavtrack_set_actor_weights(uavtrack_env *env, const float *w1, const float *
 
 /* take_action for every UAV: obs [B][N][12] (what get_local_state returned, i.e. the obs output of the
  * previous step / reset) -> actions [B][N] int32, and, if probs != NULL, the policy's probabilities
- * probs [B][N][na*nc].  Draws are keyed by (seed, env_offset + b, step_count[b], uav). */
+ * probs [B][N][na*nc].  Draws: Philox4x32-10 keyed by seed, counter (env_offset + b, step_count[b] >> 2,
+ * uav); the uniform of step s is word s & 3 of that block (24 bits), the action the first index whose
+ * cumulative probability exceeds it. */
 int uavtrack_actor_actions(uavtrack_env *env, const float *obs, uint64_t seed, int32_t mode,
                            int32_t *actions, float *probs, void *stream);
 

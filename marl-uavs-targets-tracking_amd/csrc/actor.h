@@ -35,7 +35,7 @@
 
 namespace uavtrack {
 
-constexpr int kActorMaxActions = 16;
+constexpr int kActorMaxActions = 12;                  // the reference's action space (configs: na = 12)
 constexpr int kActorObs = UAVTRACK_OBS_DIM;            // 12
 constexpr int kActorFragsPerBlock = 11;
 constexpr int kActorLdsFloats = 64 * 20;               // per wavefront: logits at a 20-float stride (conflict-free b128)
@@ -75,10 +75,16 @@ inline void pack_actor_blob(const float *w1, const float *b1, const float *w2, c
 // EVERY lane of the wavefront must reach this call together (MFMA ignores EXEC); lanes without a UAV pass
 // zeros and ignore the result.  lds: kActorLdsFloats floats private to this wavefront.
 // mode: UAVTRACK_ACTOR_SAMPLE (inverse-CDF draw) or UAVTRACK_ACTOR_ARGMAX (lowest index on ties).
+struct ActorRng {          // Philox block cache of one UAV (see the draw below)
+    Philox4 r;
+    uint32_t block;
+    bool valid;
+};
+
 template <bool WANT_PROBS>
 __device__ __forceinline__ int actor_pick(const float (&o)[kActorObs], float *lds, const float *__restrict__ weights,
                                           int HB, int A, uint64_t genv, uint32_t step, int i, uint32_t k0, uint32_t k1,
-                                          int mode, float *probs)
+                                          int mode, float *probs, ActorRng &rng)
 {
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     // ---- the 12 inputs of the 64 samples, regrouped into B fragments: lane l <- obs[16n + l%16][4s + l/16]
@@ -137,7 +143,7 @@ __device__ __forceinline__ int actor_pick(const float (&o)[kActorObs], float *ld
     __builtin_amdgcn_wave_barrier();
     float lg[kActorMaxActions];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < kActorMaxActions / 4; ++q) {
         const float4 v = *reinterpret_cast<const float4 *>(lds + lane * 20 + 4 * q);
         lg[4 * q] = v.x; lg[4 * q + 1] = v.y; lg[4 * q + 2] = v.z; lg[4 * q + 3] = v.w;
     }
@@ -145,10 +151,8 @@ __device__ __forceinline__ int actor_pick(const float (&o)[kActorObs], float *ld
 #pragma unroll
     for (int q = 0; q < kActorMaxActions; ++q) lg[q] = (q < A) ? lg[q] : -INFINITY;
     float m = lg[0];
-    int am = 0;
 #pragma unroll
-    for (int q = 1; q < kActorMaxActions; ++q)
-        if (lg[q] > m) { m = lg[q]; am = q; }
+    for (int q = 1; q < kActorMaxActions; ++q) m = fmaxf(m, lg[q]);
     float ex[kActorMaxActions], S = 0.0f;
 #pragma unroll
     for (int q = 0; q < kActorMaxActions; ++q) {
@@ -159,18 +163,32 @@ __device__ __forceinline__ int actor_pick(const float (&o)[kActorObs], float *ld
         const float inv = 1.0f / S;
         for (int q = 0; q < A; ++q) probs[q] = ex[q] * inv;
     }
-    if (mode == UAVTRACK_ACTOR_ARGMAX) return am;
-    const Philox4 r = philox4x32_10((uint32_t)genv, step, (uint32_t)i, 0x4143544Fu ^ (uint32_t)(genv >> 32), k0, k1);
-    const float target = u01(r.v[0]) * S;
+    if (mode == UAVTRACK_ACTOR_ARGMAX) {
+        int am = 0;
+#pragma unroll
+        for (int q = kActorMaxActions - 1; q >= 0; --q) am = (lg[q] == m) ? q : am;   // lowest index on ties
+        return am;
+    }
+    // One Philox block serves four consecutive steps (its four words): the generator is the costly part of
+    // the draw (40 quarter-rate integer multiplies), and a rollout caches the block across steps.
+    const uint32_t blk = step >> 2;
+    if (rng.block != blk || !rng.valid) {
+        rng.r = philox4x32_10((uint32_t)genv, blk, (uint32_t)i, 0x4143544Fu ^ (uint32_t)(genv >> 32), k0, k1);
+        rng.block = blk;
+        rng.valid = true;
+    }
+    const uint32_t word = (step & 2) ? ((step & 1) ? rng.r.v[3] : rng.r.v[2]) : ((step & 1) ? rng.r.v[1] : rng.r.v[0]);
+    const float target = u01(word) * S;
+    // first q with cumsum_q > target == number of q with cumsum_q <= target (the sums never decrease);
+    // rounding can leave even the last one <= target, hence the clamp
     float c = 0.0f;
-    int pick = A - 1;                       // rounding can leave the last cumulative sum <= target
-    bool found = false;
+    int pick = 0;
 #pragma unroll
     for (int q = 0; q < kActorMaxActions; ++q) {
         c += ex[q];
-        if (!found && c > target && q < A) { pick = q; found = true; }
+        pick += (c <= target) ? 1 : 0;
     }
-    return pick;
+    return min(pick, A - 1);
 }
 
 }  // namespace uavtrack

@@ -96,8 +96,10 @@ __global__ void __launch_bounds__(256) actor_policy_kernel(const ActorParams p)
         step = p.step_count[b];
     }
     float *pr = (valid && p.probs) ? p.probs + g * p.A : nullptr;
+    ActorRng rng;
+    rng.valid = false; rng.block = 0;
     const int act = actor_pick<true>(o, lds[threadIdx.x >> 6], p.weights, p.hblocks, p.A, (uint64_t)(p.env_offset + b),
-                                     (uint32_t)step, i, p.k0, p.k1, p.mode, pr);
+                                     (uint32_t)step, i, p.k0, p.k1, p.mode, pr, rng);
     if (valid) p.actions[g] = act;
 }
 

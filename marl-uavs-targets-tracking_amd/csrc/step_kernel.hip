@@ -427,6 +427,8 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     }
     int act = 0;
     if (GIVEN && active) act = p.actions[g];
+    ActorRng arng;
+    arng.valid = false; arng.block = 0;
     float o[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // this UAV's local state; the actor reads last step's
     if (ACTOR && active) {
         const float4 *ip = reinterpret_cast<const float4 *>(p.obs_in + g * UAVTRACK_OBS_DIM);
@@ -486,7 +488,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         if (ACTOR) {     // whole wavefronts: the two layers run on the matrix cores (actor.h)
             float *alds = reinterpret_cast<float *>(reinterpret_cast<char *>(smem4) + p.actor_lds_off) + (tid >> 6) * kActorLdsFloats;
             act = actor_pick<false>(o, alds, p.actor_w, p.actor_hblocks, p.na_total, (uint64_t)(p.env_offset + b),
-                                    (uint32_t)count, i, p.greedy_k0, p.greedy_k1, p.actor_mode, nullptr);
+                                    (uint32_t)count, i, p.greedy_k0, p.greedy_k1, p.actor_mode, nullptr, arng);
             if (active && p.actions_out) p.actions_out[tg_off] = act;
         }
 

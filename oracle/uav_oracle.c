@@ -597,12 +597,13 @@ int orc_actor_actions(const orc_config *cfg, uint64_t seed, int64_t env_offset, 
                 if (A > 1 && pr[best] - second < mg) mg = pr[best] - second;
                 actions[(size_t)b * N + i] = best;
             } else {
-                uint32_t ctr[4] = {(uint32_t)gid, (uint32_t)step_count[b], (uint32_t)i, 0x4143544Fu ^ (uint32_t)(gid >> 32)};
+                /* one Philox block per four consecutive steps, word = step & 3 (include/uavtrack.h) */
+                uint32_t ctr[4] = {(uint32_t)gid, (uint32_t)step_count[b] >> 2, (uint32_t)i, 0x4143544Fu ^ (uint32_t)(gid >> 32)};
                 uint32_t r[4];
                 double u, c = 0.0;
                 int pick = A - 1;
                 orc_philox4x32_10(ctr, key, r);
-                u = (double)u01f(r[0]);
+                u = (double)u01f(r[(uint32_t)step_count[b] & 3u]);
                 for (j = 0; j < A; ++j) {
                     c += pr[j];
                     if (j < A - 1 && fabs(c - u) < mg) mg = fabs(c - u);

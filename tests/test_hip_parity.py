@@ -550,7 +550,11 @@ def test_device_actor_vs_reference_golden_and_oracle(uavtrack):
         env.actor_actions(torch.zeros(B, N, 12, device="cuda"))
     env.set_actor(sd)
     obs = torch.from_numpy(obs_all[:B * N].reshape(B, N, 12)).cuda()
+    st = env.get_state()
+    st["step_count"] = (torch.arange(B, device="cuda") % 11).int()        # every word of the Philox block, several blocks
+    env.set_state(**st)
     sc = env.get_state()["step_count"].cpu().numpy()
+    assert sc.max() == 10
     total = 0
     for mode, seed in ((0, 5), (0, 2 ** 40 + 17), (1, 0)):
         act, probs = env.actor_actions(obs, seed=seed, mode=mode, want_probs=True)

@@ -174,8 +174,8 @@ def test_actor_restatement_matches_reference_network():
     # take_action semantics: the draw is the inverse CDF at the Philox uniform of (seed, env, step, uav)
     from oracle import philox4x32_10
     for b, i in ((0, 0), (3, 5), (B - 1, N - 1)):
-        r = philox4x32_10([b, int(sc[b]), i, 0x4143544F], [11, 0])
-        u = np.float32(r[0] >> 8) * np.float32(2.0 ** -24)
+        r = philox4x32_10([b, int(sc[b]) >> 2, i, 0x4143544F], [11, 0])
+        u = np.float32(r[int(sc[b]) & 3] >> 8) * np.float32(2.0 ** -24)
         want = int(np.searchsorted(np.cumsum(probs[b, i]), u, side="right"))
         assert act[b, i] == min(want, 11)
     # different keys -> different draws; argmax mode is the mode of the distribution

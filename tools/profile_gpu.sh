@@ -17,5 +17,8 @@ echo "== pmc sq1"; rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS
 echo "== pmc sq2"; rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc_sq2 -- python3 $R/bench.py $BENCH_ARGS > /dev/null 2> $OUT/pmc_sq2.err || { tail -5 $OUT/pmc_sq2.err; exit 1; }
 echo "== pmc fetch"; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py $BENCH_ARGS > /dev/null 2> $OUT/pmc_fetch.err || { tail -5 $OUT/pmc_fetch.err; exit 1; }
 echo "== pmc write"; rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py $BENCH_ARGS > /dev/null 2> $OUT/pmc_write.err || { tail -5 $OUT/pmc_write.err; exit 1; }
+if [ -n "$PROFILE_MFMA" ]; then
+echo "== pmc mfma"; rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/pmc_mfma -- python3 $R/bench.py $BENCH_ARGS > /dev/null 2> $OUT/pmc_mfma.err || { tail -5 $OUT/pmc_mfma.err; }
+fi
 find $OUT -name '*.csv' | head -40
 du -sh $OUT

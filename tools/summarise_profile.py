@@ -88,6 +88,9 @@ for k, c in out.items():
     if "SQ_ACTIVE_INST_VALU" in c:
         lines.append(f"- ACTIVE_INST_VALU {c['SQ_ACTIVE_INST_VALU']:.3g}, ACTIVE_INST_LDS {c.get('SQ_ACTIVE_INST_LDS',0):.3g}, ACTIVE_INST_ANY {c.get('SQ_ACTIVE_INST_ANY',0):.3g}, "
                      f"WAIT_INST_LDS {c.get('SQ_WAIT_INST_LDS',0):.3g}, LDS_BANK_CONFLICT {c.get('SQ_LDS_BANK_CONFLICT',0):.3g} / LDS_IDX_ACTIVE {c.get('SQ_LDS_IDX_ACTIVE',0):.3g}")
+    if c.get("SQ_INSTS_MFMA"):
+        lines.append(f"- MFMA: {c['SQ_INSTS_MFMA']:.4g} instructions, SQ_VALU_MFMA_BUSY_CYCLES {c.get('SQ_VALU_MFMA_BUSY_CYCLES',0):.4g} "
+                     f"({c.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/c['SQ_INSTS_MFMA']:.1f} busy cycles per MFMA)")
     lines.append("")
     lines.append("all counters: " + ", ".join(f"{n}={v:.4g}" for n, v in sorted(c.items()) if not n.startswith("_")))
 open(f"profiles/{tag}_summary.md", "w").write("\n".join(lines) + "\n")
