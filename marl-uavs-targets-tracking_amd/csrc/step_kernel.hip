@@ -846,7 +846,9 @@ Geometry plan_geometry(const uavtrack_config &cfg, int n_simd)
         for (int wgs : kLarge)
             if (feasible(wgs) && util_of(wgs) > best_util) best_util = util_of(wgs);
         bool small_grid = false;
-        if (feasible(64)) {
+        // (MAAC-R keeps the larger groups: its pair emission costs one global atomic per workgroup-step, and
+        // four times the workgroups measured 15.8 instead of 5.2 us per step at 4096 envs)
+        if (feasible(64) && cfg.reward_mode != UAVTRACK_REWARD_PMI) {
             const long waves = (cfg.n_envs + 64 / N - 1) / (64 / N);
             small_grid = waves <= 3L * (n_simd > 0 ? n_simd : 1024);
         }
