@@ -612,3 +612,62 @@ def test_fused_actor_rollout_equals_stepwise(uavtrack, N, M, coop, mode):
     first = c.run_actor(8, o0, seed=21, mode=mode)
     second = c.run_actor(T - 8, first["obs"][-1].contiguous(), seed=21, mode=mode)
     assert torch.equal(second["obs"][-1], fused["obs"][-1]) and torch.equal(second["actions"], fused["actions"][8:])
+
+
+def test_plain_c_client_matches_python_host_layer(uavtrack, tmp_path):
+    """tests/abi/abi_roundtrip.c (gcc, C99, hipMalloc'd buffers, no torch) drives libuavtrack.so through
+    include/uavtrack.h; its checksums equal the Python host layer's on the same seed and actions, bit for bit."""
+    import subprocess
+    from test_host_cpu import build_abi_client
+    exe = build_abi_client(tmp_path)
+    B, N, M, T, seed = 96, 20, 10, 7, 42
+    r = subprocess.run([exe, str(B), str(N), str(M), str(T), str(seed)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    got = r.stdout.split()
+
+    def fnv1a(buf: bytes) -> int:
+        h = 1469598103934665603
+        for chunk in (buf,):
+            for byte in chunk:
+                h = ((h ^ byte) * 1099511628211) & (2 ** 64 - 1)
+        return h
+    env = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(n_envs=B, n_uav=N, m_targets=M))
+    env.reset(seed=seed)
+    covered = 0
+    g = np.arange(B * N, dtype=np.int64)
+    for t in range(T):
+        act = ((g * 7 + t * 3) % 12).astype(np.int32).reshape(B, N)
+        obs, rew, _ = env.step(torch.from_numpy(act))
+        covered += int(env.info["covered"].sum())
+    assert got[1] == f"{fnv1a(obs.cpu().numpy().tobytes()):016x}"
+    assert got[3] == f"{fnv1a(rew.cpu().numpy().tobytes()):016x}"
+    assert int(got[5]) == covered
+
+
+def test_bench_contract_line(uavtrack):
+    """bench.py prints ONE JSON line with the driver's keys, the roofline and cpu_baseline objects, and a value
+    that agrees with its own ms_per_step (short run: 400 timed steps, 2 s of CPU baseline)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "400", "--warmup", "200",
+                        "--cpu-seconds", "2", "--no-extras"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "env agent-steps/sec" and d["unit"] == "agent-steps/s" and d["n_gpus"] == 1
+    assert d["steps"] == 400 and d["warmup"] == 200 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 4096 * 20 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert d["value"] > 1e9                                   # > 100x the 10 M north-star floor
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.05 < rf["frac"] < 1.0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 1e5 and "sample" in cb

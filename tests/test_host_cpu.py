@@ -231,3 +231,27 @@ def test_pmi_training_data_path():
     assert torch.isfinite(pmi_contrastive_loss(torch.tensor([-200.0]), torch.tensor([200.0])))   # the naive form overflows
     batches = list(pmi_batches(sel, 16))
     assert len(batches) == 3 and batches[0][0].shape == (16, 12) and torch.equal(batches[1][1], sel[16:32, 1])
+
+
+def build_abi_client(tmp_path):
+    """gcc (C99, no C++, no Python) against include/uavtrack.h + libuavtrack.so + the HIP runtime."""
+    import subprocess
+    libdir = os.path.join(ROOT, "marl-uavs-targets-tracking_amd", "uavtrack")
+    exe = os.path.join(str(tmp_path), "abi_roundtrip")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+                    os.path.join(ROOT, "tests", "abi", "abi_roundtrip.c"), "-o", exe, "-L/opt/rocm/lib", "-lamdhip64",
+                    "-L" + libdir, "-luavtrack", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath," + libdir], check=True)
+    return exe
+
+
+def test_c_abi_builds_from_plain_c_and_fails_loudly_without_gpu(tmp_path):
+    """The boundary is a real C ABI: a C99 translation unit compiles against the header with -Werror, links,
+    and -- in this GPU-less container -- gets status != 0 plus uavtrack_last_error(), not a fallback."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("covered by the GPU test")
+    exe = build_abi_client(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 3, (r.returncode, r.stderr)
+    assert "no HIP device" in r.stderr and "no CPU fallback" in r.stderr
