@@ -198,7 +198,8 @@ int uavtrack_actor_actions(uavtrack_env *env, const float *obs, uint64_t seed, i
  * observation the policy sees at the first step.  Bitwise identical to T x (uavtrack_actor_actions,
  * uavtrack_step).  actions_out (nullable) [T][B][N]; the other outputs are those of uavtrack_step_many,
  * i.e. the (state, action, reward, next_state) transitions of train.py:176-180 land in
- * obs[t-1] / actions_out[t] / reward[t] / obs[t].  Reward modes RAW / MEAN. */
+ * obs[t-1] / actions_out[t] / reward[t] / obs[t].  With reward_mode PMI the launch is chunked like
+ * uavtrack_step_many (rollout, pair scorer, softmax mix per chunk); the policy never reads rewards. */
 int uavtrack_run_actor(uavtrack_env *env, int32_t T, uint64_t seed, int32_t mode, const float *obs_in,
                        int32_t *actions_out, float *obs, float *reward, float *terms,
                        int32_t *covered, uint8_t *done, float *ep_sums, void *stream);

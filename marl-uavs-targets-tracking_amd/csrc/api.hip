@@ -337,13 +337,22 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
     return 0;
 }
 
+// Where a rollout's actions come from: the caller's tensor, or the in-kernel actor (uavtrack_run_actor).
+struct PolicyArgs {
+    int policy = kPolicyGiven;
+    const float *obs_in = nullptr;     // actor: observation seen at the first step
+    int32_t *actions_out = nullptr;    // actor: chosen actions [T][B][N], nullable
+    uint64_t seed = 0;
+    int32_t mode = 0;
+};
+
 static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float *obs, float *reward, float *terms,
                      int32_t *covered, uint8_t *done, float *ep_sums, void *stream, const char *who,
-                     bool accumulate = false)
+                     bool accumulate = false, const PolicyArgs &pol = PolicyArgs())
 {
     if (!env) return fail("%s: null handle", who);
     if (T < 1) return fail("%s: T must be >= 1 (got %d)", who, T);
-    if (!actions) return fail("%s: actions is null", who);
+    if (pol.policy == kPolicyGiven && !actions) return fail("%s: actions is null", who);
     if (!reward) return fail("%s: reward is null", who);
     HIP_TRY(hipSetDevice(env->cfg.device_id));
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -353,10 +362,16 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
     p.covered = covered; p.done = done; p.ep_sums = ep_sums;
     p.pairs = nullptr; p.pair_count = nullptr;
     p.ep_accumulate = accumulate ? 1 : 0;
-    p.actions_out = nullptr;
+    p.actions_out = pol.actions_out;
+    p.env_offset = env->cfg.env_offset;
+    if (pol.policy == kPolicyActor) {
+        p.greedy_k0 = (uint32_t)pol.seed; p.greedy_k1 = (uint32_t)(pol.seed >> 32);
+        p.obs_in = pol.obs_in; p.actor_w = env->actor_w; p.actor_hblocks = actor_blocks(env->actor_hidden);
+        p.actor_mode = pol.mode;
+    }
     if (env->cfg.reward_mode != UAVTRACK_REWARD_PMI) {
         p.T = T;
-        HIP_TRY(launch_rollout(env, p, st));
+        HIP_TRY(launch_rollout(env, p, st, pol.policy));
         return 0;
     }
     // MAAC-R.  Rewards never feed back into the dynamics, so scoring is deferred: a chunk of steps is
@@ -379,11 +394,15 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
         float *reward_t = reward + (size_t)t0 * BN;
         int32_t *covered_t = covered ? covered + (size_t)t0 * c.n_envs : nullptr;
         p.T = n;
-        p.actions = actions + (size_t)t0 * BN;
+        p.actions = actions ? actions + (size_t)t0 * BN : nullptr;
+        p.actions_out = pol.actions_out ? pol.actions_out + (size_t)t0 * BN : nullptr;
         p.obs = obs_t; p.reward = reward_t; p.terms = terms_t;
         p.covered = covered_t;
         p.done = done ? done + (size_t)t0 * c.n_envs : nullptr;
-        HIP_TRY(launch_rollout(env, p, st));
+        HIP_TRY(launch_rollout(env, p, st, pol.policy));
+        // the actor of the next chunk starts from this chunk's last observation (a lane reads its own row
+        // once, at launch start, before it writes anything: the scratch buffer may be reused in place)
+        p.obs_in = obs_t + (size_t)(n - 1) * BN * UAVTRACK_OBS_DIM;
         HIP_TRY(launch_pmi_score(env, obs_t, st));
         HIP_TRY(launch_pmi_finalize(env, n, reward_t, st));
         if (ep_sums) {
@@ -502,24 +521,12 @@ int uavtrack_run_actor(uavtrack_env *env, int32_t T, uint64_t seed, int32_t mode
     if (!env->actor_w) return fail("uavtrack_run_actor: needs uavtrack_set_actor_weights first");
     if (mode != UAVTRACK_ACTOR_SAMPLE && mode != UAVTRACK_ACTOR_ARGMAX)
         return fail("uavtrack_run_actor: mode %d is neither UAVTRACK_ACTOR_SAMPLE nor UAVTRACK_ACTOR_ARGMAX", mode);
-    if (env->cfg.reward_mode == UAVTRACK_REWARD_PMI)
-        return fail("uavtrack_run_actor: reward modes RAW / MEAN only; with MAAC-R alternate uavtrack_actor_actions "
-                    "and uavtrack_step (its scoring is deferred per launch)");
     if (obs_in == obs && T > 1)
-        return fail("uavtrack_run_actor: obs_in must not alias obs when T > 1 (obs[0] is written while other "
-                    "workgroups may still read obs_in)");
-    HIP_TRY(hipSetDevice(env->cfg.device_id));
-    StepParams p = env->base;
-    p.T = T;
-    p.actions = nullptr; p.actions_out = actions_out;
-    p.obs = obs; p.reward = reward; p.terms = terms; p.pose_out = nullptr;
-    p.covered = covered; p.done = done; p.ep_sums = ep_sums;
-    p.pairs = nullptr; p.pair_count = nullptr; p.ep_accumulate = 0;
-    p.env_offset = env->cfg.env_offset;
-    p.greedy_k0 = (uint32_t)seed; p.greedy_k1 = (uint32_t)(seed >> 32);
-    p.obs_in = obs_in; p.actor_w = env->actor_w; p.actor_hblocks = actor_blocks(env->actor_hidden); p.actor_mode = mode;
-    HIP_TRY(launch_rollout(env, p, static_cast<hipStream_t>(stream), kPolicyActor));
-    return 0;
+        return fail("uavtrack_run_actor: obs_in must not alias obs when T > 1 (pass the previous launch's last rows, "
+                    "or a copy)");
+    PolicyArgs pol;
+    pol.policy = kPolicyActor; pol.obs_in = obs_in; pol.actions_out = actions_out; pol.seed = seed; pol.mode = mode;
+    return run_steps(env, T, nullptr, obs, reward, terms, covered, done, ep_sums, stream, "uavtrack_run_actor", false, pol);
 }
 
 int uavtrack_pmi_pairs_scored(uavtrack_env *env, uint64_t *out, void *stream)

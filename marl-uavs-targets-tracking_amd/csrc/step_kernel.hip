@@ -783,9 +783,12 @@ KernelFn pick_mode(int mode, bool z3, int policy)
         return mode == UAVTRACK_REWARD_MEAN ? rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, false, kPolicyGreedy>
                                             : rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, false, kPolicyGreedy>;
     }
-    if (policy == kPolicyActor) {    // na*nc <= 12: planar; MAAC / MAAC-G rewards
-        return mode == UAVTRACK_REWARD_MEAN ? rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, false, kPolicyActor>
-                                            : rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, false, kPolicyActor>;
+    if (policy == kPolicyActor) {    // na*nc <= 12: planar
+        switch (mode) {
+        case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, false, kPolicyActor>;
+        case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, UAVTRACK_REWARD_PMI, false, kPolicyActor>;
+        default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, false, kPolicyActor>;
+        }
     }
     if (z3) {
         switch (mode) {

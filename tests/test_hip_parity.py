@@ -580,14 +580,22 @@ def test_device_actor_vs_reference_golden_and_oracle(uavtrack):
     assert (p > 0.02).sum() >= 3               # the golden policy is not degenerate
 
 
-@pytest.mark.parametrize("N,M,coop,mode", [(20, 10, 0.0, 0), (20, 10, 0.3, 0), (5, 3, 0.0, 1), (7, 4, 0.3, 0), (50, 25, 0.0, 0)])
-def test_fused_actor_rollout_equals_stepwise(uavtrack, N, M, coop, mode):
-    """uavtrack_run_actor (actor + environment, T steps, one launch) == T x (uavtrack_actor_actions,
-    uavtrack_step), bit for bit -- actions, observations, rewards, coverage, final state, episode sums."""
+@pytest.mark.parametrize("N,M,coop,mode,pmi", [(20, 10, 0.0, 0, False), (20, 10, 0.3, 0, False), (5, 3, 0.0, 1, False),
+                                               (7, 4, 0.3, 0, False), (50, 25, 0.0, 0, False), (20, 10, 0.3, 0, True),
+                                               (9, 5, 0.3, 0, True)])
+def test_fused_actor_rollout_equals_stepwise(uavtrack, pmi_state_dict, monkeypatch, N, M, coop, mode, pmi):
+    """uavtrack_run_actor (actor + environment, T steps, one launch -- one launch triple per chunk with MAAC-R)
+    == T x (uavtrack_actor_actions, uavtrack_step), bit for bit -- actions, observations, rewards, coverage,
+    final state, episode sums."""
     _, sd = golden_actor()
-    cfg = uavtrack.EnvConfig(n_envs=70, n_uav=N, m_targets=M, cooperative=coop, x_max=1100.0, y_max=900.0, env_offset=9)
+    if pmi:
+        monkeypatch.setenv("UAVTRACK_PMI_SCRATCH_MB", "1")      # several chunks per rollout: the actor's input is handed on
+    cfg = uavtrack.EnvConfig(n_envs=70, n_uav=N, m_targets=M, cooperative=coop, x_max=1100.0, y_max=900.0, env_offset=9,
+                             reward_mode=uavtrack.RewardMode.PMI if pmi else None)
     a, b = uavtrack.BatchedUavEnv(cfg), uavtrack.BatchedUavEnv(cfg)
     a.set_actor(sd); b.set_actor(sd)
+    if pmi:
+        a.set_pmi(pmi_state_dict); b.set_pmi(pmi_state_dict)
     obs0 = a.reset(seed=6)
     obs = b.reset(seed=6).clone()
     T = 19
@@ -608,6 +616,8 @@ def test_fused_actor_rollout_equals_stepwise(uavtrack, N, M, coop, mode):
     # continuing from the last observation == one longer rollout
     c = uavtrack.BatchedUavEnv(cfg)
     c.set_actor(sd)
+    if pmi:
+        c.set_pmi(pmi_state_dict)
     o0 = c.reset(seed=6)
     first = c.run_actor(8, o0, seed=21, mode=mode)
     second = c.run_actor(T - 8, first["obs"][-1].contiguous(), seed=21, mode=mode)
