@@ -156,7 +156,10 @@ def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, en
     out = {}
     gather = None
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        gather = lambda ep: uavtrack.gather_rollout_summary(ep, n_envs_total=total_envs)
+        # asynchronous: the collective runs on RCCL's stream from a private copy, the next rollout does not wait
+        # for it (nor for a slower rank); every handle is waited on before the clock stops
+        pending = []
+        gather = lambda ep: pending.append(uavtrack.gather_rollout_summary_async(ep, n_envs_total=total_envs))
     horizon = env.cfg.horizon
     warm_plan, pos = launch_plan(warmup, rollout, horizon, 0)
     timed_plan, _ = launch_plan(steps, rollout, horizon, pos)
@@ -174,6 +177,10 @@ def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, en
             out[T]["actions"] = torch.empty(T, B, args.n_uav, dtype=torch.int32, device=device)
     obs0 = env.reset(seed=args.seed)
     _, obs0 = run_rollouts(env, actions, warm_plan, 0, out, gather=gather, policy=args.policy, obs=obs0)
+    if gather is not None:
+        for h in pending:
+            h.wait()
+        pending.clear()
     torch.cuda.synchronize(device)
     if gather is not None:
         dist.barrier()
@@ -181,6 +188,9 @@ def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, en
     pairs0 = env.pmi_pairs_scored() if args.reward == "pmi" else 0
     t0 = time.perf_counter()
     launches, _ = run_rollouts(env, actions, timed_plan, pos, out, events=events, gather=gather, policy=args.policy, obs=obs0)
+    if gather is not None:
+        summaries = [h.wait() for h in pending]
+        assert all(s.shape[0] == total_envs for s in summaries)
     torch.cuda.synchronize(device)
     if gather is not None:
         dist.barrier()
@@ -311,7 +321,7 @@ def main():
                                      "Categorical sample (uavtrack_run_actor), closed loop"}[args.policy],
                 "outputs": "obs[T,B,N,12] reward[T,B,N] terms[T,3,B,N] covered[T,B] done[T,B] ep_sums[B,5], all written",
                 "parallelism": (f"env-sharded x{world}, {'RCCL' if args.backend == 'nccl' else args.backend} "
-                                f"all-gather of ep_sums per rollout") if world > 1 else "1 GPU",
+                                f"all-gather of ep_sums per rollout, asynchronous (overlaps the next rollout)") if world > 1 else "1 GPU",
                 "geometry": res["geometry"],
             },
             "roofline": {

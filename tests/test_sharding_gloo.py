@@ -36,7 +36,13 @@ def _worker(rank, world, port, total, q):
         ep[:, 0] += out["reward"].mean(1)
         ep[:, 1:4] += out["terms"].mean(2).T
         ep[:, 4] += out["covered"]
+    # asynchronous form: start the exchange, overwrite the source (as the next rollout would), then wait
+    from uavtrack.sharding import gather_rollout_summary_async
+    src = torch.from_numpy(ep.copy())
+    handle = gather_rollout_summary_async(src, n_envs_total=total)
+    src.zero_()
     full = gather_rollout_summary(torch.from_numpy(ep), n_envs_total=total)
+    assert torch.equal(handle.wait(), full) and handle.wait() is handle.wait()
     if rank == 0:
         q.put(full.numpy())
     dist.barrier()
