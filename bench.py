@@ -59,6 +59,8 @@ def parse():
                     help="where actions come from: pre-sampled (the headline workload), the fused greedy baseline "
                          "(uavtrack_run_greedy) or the fused FnnPolicyNet actor (uavtrack_run_actor, hidden --actor-hidden)")
     ap.add_argument("--actor-hidden", type=int, default=128)
+    ap.add_argument("--box", type=float, default=2000.0,
+                    help="side of the square field in metres (reference: 2000; 500 = the dense MAAC-R worst case of SURVEY 8d)")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip per-step-launch and saturating-batch legs")
@@ -92,7 +94,8 @@ def synthetic_pmi_state_dict(hidden, seed=42):
 def make_env(uavtrack, args, B, device, env_offset=0):
     nc = 3 if args.dim == 3 else 1
     mode = {"raw": uavtrack.RewardMode.RAW, "mean": uavtrack.RewardMode.MEAN, "pmi": uavtrack.RewardMode.PMI}[args.reward]
-    cfg = uavtrack.EnvConfig(n_envs=B, n_uav=args.n_uav, m_targets=args.m_targets, dim=args.dim, nc=nc,
+    cfg = uavtrack.EnvConfig(n_envs=B, n_uav=args.n_uav, m_targets=args.m_targets, dim=args.dim,
+                             x_max=getattr(args, "box", 2000.0), y_max=getattr(args, "box", 2000.0), nc=nc,
                              cooperative=args.cooperative, reward_mode=mode,
                              horizon=args.rollout if args.rollout > 1 else 200, env_offset=env_offset)
     env = uavtrack.BatchedUavEnv(cfg, device)
@@ -227,7 +230,7 @@ def cpu_baseline(args, seconds):
     N, M = args.n_uav, args.m_targets
 
     def run(B, T, threads):
-        env = OracleEnv(OracleConfig(n_envs=B, n_uav=N, m_targets=M, cooperative=args.cooperative,
+        env = OracleEnv(OracleConfig(n_envs=B, n_uav=N, m_targets=M, cooperative=args.cooperative, x_max=args.box, y_max=args.box,
                                      dim=args.dim, nc=3 if args.dim == 3 else 1), n_threads=threads)
         if args.reward == "pmi":
             from oracle import OraclePmi
@@ -311,6 +314,7 @@ def main():
                                "pmi": f"MAAC-R reciprocal (PMI H={args.pmi_hidden}) reward"}[args.reward]
                             + (f" (BASELINE configs[{4 if world > 1 else (3 if args.dim == 3 else {'raw': 1, 'mean': 1, 'pmi': 2}[args.reward])}])"),
                 "envs_total": world * B,
+                "box_m": args.box,
                 "launch": (f"{ {'given': 'uavtrack_step_many', 'greedy': 'uavtrack_run_greedy', 'actor': 'uavtrack_run_actor'}[args.policy] }, {args.rollout} steps per call, reset between rollouts"
                            + ("; MAAC-R issues 3 kernels per step (fused step, MFMA pair scorer, softmax mix)"
                               if args.reward == "pmi" else " (one kernel launch per call)"))
