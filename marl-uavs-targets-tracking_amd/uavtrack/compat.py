@@ -7,6 +7,7 @@ that train.operate_epoch-style loops and the MAAC / MAAC-R actors run unchanged:
     next_states, reward, covered = env.step(config, pmi, actions)    # train.py:176
     env.n_uav, env.get_states(), env.position, env.covered_target_num,
     env.save_position(dir, i), env.save_covered_num(dir, i)          # train.py:187,287-288
+    uav.get_action_by_direction(env.target_list, env.uav_list)       # train.py:350 (C-METHOD, train.run_epoch)
 
 One reference environment is a batch of one on the GPU; every number it returns comes
 from the HIP kernels through the C ABI (uavtrack.BatchedUavEnv).  `n_envs > 1` keeps the
@@ -34,6 +35,13 @@ class _UavView:
 
     def get_local_state(self) -> np.ndarray:
         return self._env._obs[self._i].copy()
+
+    def get_action_by_direction(self, target_list=None, uav_list=None) -> int:
+        """The C-METHOD baseline the way train.run_epoch calls it (train.py:350; uav.py:324-369): one call per
+        UAV per step.  The library evaluates the policy for all UAVs at once (uavtrack_greedy_actions) on the
+        first call of a step; the other N - 1 calls read the cached row.  The arguments are accepted for call
+        compatibility -- the policy works on the environment's own state."""
+        return self._env._greedy_action(self._i)
 
     x = property(lambda self: float(self._env._host_state()["ux"][self._i]))
     y = property(lambda self: float(self._env._host_state()["uy"][self._i]))
@@ -73,6 +81,8 @@ class Environment:
         self._state_cache = None
         self._pmi_id = None
         self._episode = 0
+        self._greedy_cache = None
+        self._greedy_seed: Optional[int] = None
 
     # -- helpers ----------------------------------------------------------------------
     def _mode_for(self, config, pmi) -> RewardMode:
@@ -122,9 +132,19 @@ class Environment:
         self.target_list = [_TargetView(self, k) for k in range(self.m_targets)]
         self.position = {'all_uav_xs': [], 'all_uav_ys': [], 'all_target_xs': [], 'all_target_ys': []}
         self.covered_target_num = []
+        self._greedy_cache = None
 
     def get_states(self) -> List[np.ndarray]:
         return [self._obs[i].copy() for i in range(self.n_uav)]   # environment.py:109-118
+
+    def _greedy_action(self, i: int) -> int:
+        step = len(self.covered_target_num)
+        if self._greedy_cache is None or self._greedy_cache[0] != (self._episode, step):
+            if self._greedy_seed is None:
+                self._greedy_seed = random.getrandbits(63)     # pinned by random.seed like everything else
+            acts = self._env.greedy_actions(seed=self._greedy_seed)[0].cpu().numpy()
+            self._greedy_cache = ((self._episode, step), acts)
+        return int(self._greedy_cache[1][i])
 
     def step(self, config, pmi, actions):
         mode = self._mode_for(config, pmi)

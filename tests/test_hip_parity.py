@@ -434,6 +434,14 @@ def test_compat_environment_reference_call_shapes(uavtrack):
         assert covered == int(z["covered"][0, t])
     assert len(env.covered_target_num) == 10 and len(env.position["all_uav_xs"]) == 10
     assert abs(env.uav_list[0].x - z["ux"][0, 10, 0]) < 1e-2
+    # train.run_epoch's inner loop (train.py:346-352): one get_action_by_direction call per UAV, then step
+    for _ in range(3):
+        action_list = [uav.get_action_by_direction(env.target_list, env.uav_list) for uav in env.uav_list]
+        assert all(isinstance(a, int) and 0 <= a < 12 for a in action_list)
+        want = env._env.greedy_actions(seed=env._greedy_seed)[0].cpu().numpy()     # all UAVs from ONE policy call
+        np.testing.assert_array_equal(action_list, want)
+        env.step(ref_cfg, None, action_list)
+    assert len(env.covered_target_num) == 13
 
 
 def test_closed_loop_rollout_graph_equals_eager(uavtrack):
