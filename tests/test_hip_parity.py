@@ -689,3 +689,16 @@ def test_bench_contract_line(uavtrack):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.05 < rf["frac"] < 1.0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 1e5 and "sample" in cb
+
+
+def test_example_training_loop_runs(uavtrack):
+    """examples/train_maac.py: fused rollouts -> device replay -> PyTorch TD actor-critic update -> weight upload,
+    a few iterations end to end; returns stay finite."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("train_maac", os.path.join(ROOT, "examples", "train_maac.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    hist = mod.main(["--envs", "64", "--iters", "3", "--steps", "40", "--batch", "4096", "--updates", "2"])
+    assert len(hist) == 3 and all(np.isfinite(h) for h in hist)
