@@ -148,8 +148,10 @@ __device__ __forceinline__ int actor_pick(const float (&o)[kActorObs], float *ld
         lg[4 * q] = v.x; lg[4 * q + 1] = v.y; lg[4 * q + 2] = v.z; lg[4 * q + 3] = v.w;
     }
     __builtin_amdgcn_wave_barrier();                 // the next call's input staging must not overtake these reads
+    if (A < kActorMaxActions) {                      // uniform; the reference's na = 12 fills every slot
 #pragma unroll
-    for (int q = 0; q < kActorMaxActions; ++q) lg[q] = (q < A) ? lg[q] : -INFINITY;
+        for (int q = 0; q < kActorMaxActions; ++q) lg[q] = (q < A) ? lg[q] : -INFINITY;
+    }
     float m = lg[0];
 #pragma unroll
     for (int q = 1; q < kActorMaxActions; ++q) m = fmaxf(m, lg[q]);
