@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Long teacher-forced comparison HIP vs oracle (GPU box; not part of the test suite): many envs,
+"""Long teacher-forced comparison HIP vs oracle (GPU box; run by hand: `python tests/soak.py`, not collected by pytest): many envs,
 many steps, several boxes, so that rare paths (wall mirrors, heading wraps, near-origin weights,
 UAVs outside the box, crowded neighbourhoods) all occur."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ -> repo root
 sys.path[:0] = [ROOT, os.path.join(ROOT, "marl-uavs-targets-tracking_amd")]
 import torch
 import uavtrack
