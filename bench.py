@@ -247,10 +247,13 @@ def cpu_baseline(args, seconds):
     T = 200
     B = int(max(cores, min(4096, rN * seconds * 0.7 / (N * T))))
     B1 = int(max(1, min(4096, r1 * seconds * 0.3 / (N * T))))
-    vN = run(B, T, cores)
+    # whole episodes of the (capped) workload, repeated until ~20 core-seconds have been spent on this leg
+    reps = int(max(1, min(16, round(20.0 / cores / (B * N * T / rN)))))
+    rates = [run(B, T, cores) for _ in range(reps)]         # each: the stepping loop of one episode batch
+    vN = reps / sum(1.0 / r for r in rates)                  # total agent-steps / total stepping time
     v1 = run(B1, T, 1)
     return dict(value=vN, unit="agent-steps/s", cores=cores, kind="port",
-                sample=f"{B} envs x {N} UAVs x {M} targets x {T} steps, fp64 scalar C oracle, {cores} OpenMP threads",
+                sample=f"{reps} x ({B} envs x {N} UAVs x {M} targets x {T} steps), fp64 scalar C oracle, {cores} OpenMP threads",
                 value_1core=v1, sample_1core=f"{B1} envs x {T} steps, 1 thread")
 
 
