@@ -702,3 +702,47 @@ def test_example_training_loop_runs(uavtrack):
     spec.loader.exec_module(mod)
     hist = mod.main(["--envs", "64", "--iters", "3", "--steps", "40", "--batch", "4096", "--updates", "2"])
     assert len(hist) == 3 and all(np.isfinite(h) for h in hist)
+
+
+def test_create_destroy_does_not_leak_and_errors_are_reported(uavtrack, pmi_state_dict):
+    """300 create / use / destroy cycles leave device memory where it was (every mode allocates its scratch);
+    misuse comes back as RuntimeError with the library's message, never as a crash or a silent fallback."""
+    _, sd = golden_actor()
+
+    def cycle(mode):
+        cfg = uavtrack.EnvConfig(n_envs=32, n_uav=20, m_targets=10, cooperative=0.3 if mode else 0.0,
+                                 reward_mode=uavtrack.RewardMode.PMI if mode == 2 else None)
+        env = uavtrack.BatchedUavEnv(cfg)
+        if mode == 2:
+            env.set_pmi(pmi_state_dict)
+        env.set_actor(sd)
+        obs = env.reset(seed=1)
+        env.run_actor(3, obs, seed=2)
+        env.close()
+    for m in (0, 1, 2):
+        cycle(m)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for k in range(300):
+        cycle(k % 3)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, (free0, free1)
+
+    env = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(n_envs=4, n_uav=5, m_targets=3, reward_mode=uavtrack.RewardMode.PMI, cooperative=0.3))
+    env.reset(seed=0)
+    with pytest.raises(RuntimeError, match="uavtrack_set_pmi_weights first"):
+        env.step(torch.zeros(4, 5, dtype=torch.int32))
+    with pytest.raises((RuntimeError, ValueError)):
+        env.step(torch.zeros(4, 6, dtype=torch.int32))                     # wrong shape
+    with pytest.raises(RuntimeError, match="hidden 96 not built"):
+        env.set_pmi(random_pmi_state_dict(96, 0))
+    with pytest.raises(ValueError, match="do not match"):
+        env.set_actor({"fc1.weight": torch.zeros(8, 11), "fc1.bias": torch.zeros(8),
+                       "fc2.weight": torch.zeros(12, 8), "fc2.bias": torch.zeros(12)})
+    env3 = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(n_envs=2, n_uav=4, m_targets=2, dim=3, nc=3, z_max=300.0))
+    with pytest.raises(RuntimeError, match="36 actions"):
+        env3.set_actor({"fc1.weight": torch.zeros(8, 12), "fc1.bias": torch.zeros(8),
+                        "fc2.weight": torch.zeros(36, 8), "fc2.bias": torch.zeros(36)})
+    with pytest.raises(RuntimeError, match="planar"):
+        env3.greedy_actions()
