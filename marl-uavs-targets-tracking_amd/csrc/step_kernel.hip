@@ -832,12 +832,19 @@ Geometry plan_geometry(const uavtrack_config &cfg, int n_simd)
     // 0.689 ms vs 0.751 ms per 200 steps); past that 4-wave groups win (65 536 envs 39.6 vs 33.9 G).
     static const int kLarge[] = {256, 128, 512, 64};
     static const int kSmall[] = {64, 128, 256, 512};
+    // whole environments per workgroup: as many as there are lanes for, fewer when their tables would not fit
+    // the 64 KB of LDS a workgroup may have (few UAVs, many targets: N = 1, M = 70 fits 58 environments, not 64)
+    auto envs_of = [&](int wgs) {
+        int E = wgs / N;
+        while (E > 1 && lds_bytes_for(E, N, cfg.m_targets, cfg.dim == 3) > 64 * 1024) --E;
+        return E;
+    };
     auto feasible = [&](int wgs) {
-        const int E = wgs / N;
-        return E >= 1 && lds_bytes_for(E, N, cfg.m_targets, cfg.dim == 3) <= 64 * 1024;   // e.g. N = 1, many targets
+        const int E = envs_of(wgs);
+        return E >= 1 && lds_bytes_for(E, N, cfg.m_targets, cfg.dim == 3) <= 64 * 1024;
     };
     auto util_of = [&](int wgs) {
-        const int E = wgs / N;
+        const int E = envs_of(wgs);
         const int Euse = E < cfg.n_envs ? E : cfg.n_envs;
         return (double)Euse * N / wgs;
     };
@@ -852,7 +859,7 @@ Geometry plan_geometry(const uavtrack_config &cfg, int n_simd)
         // (MAAC-R keeps the larger groups: its pair emission costs one global atomic per workgroup-step, and
         // four times the workgroups measured 15.8 instead of 5.2 us per step at 4096 envs)
         if (feasible(64) && cfg.reward_mode != UAVTRACK_REWARD_PMI) {
-            const long waves = (cfg.n_envs + 64 / N - 1) / (64 / N);
+            const long waves = (cfg.n_envs + envs_of(64) - 1) / envs_of(64);
             small_grid = waves <= 3L * (n_simd > 0 ? n_simd : 1024);
         }
         // (the band is a little wider on a small grid: N = 10 at 4096 envs measured 0.409 ms with
@@ -862,7 +869,7 @@ Geometry plan_geometry(const uavtrack_config &cfg, int n_simd)
     }
     if (!best) return g;
     g.wgs = best;
-    g.envs_per_wg = best / N;
+    g.envs_per_wg = envs_of(best);
     g.groups = (cfg.n_envs + g.envs_per_wg - 1) / g.envs_per_wg;
     g.lds_bytes = lds_bytes_for(g.envs_per_wg, N, cfg.m_targets, cfg.dim == 3);
     pick_kernel(N, cfg.m_targets, cfg.reward_mode, cfg.dim == 3, &g.specialised);

@@ -25,6 +25,8 @@ def run(B, N, M, coop, box, steps, seed, dim=2):
         ref = orc.step(act)
         ok = ref["margin"] > 1e-3
         skipped += int((~ok).sum()); total += B
+        if not ok.any():
+            continue
         o = obs.cpu().numpy(); r = rew.cpu().numpy(); tm = env.info["terms"].cpu().numpy(); cv = env.info["covered"].cpu().numpy()
         # near the origin the uav.py:165 weight 1/min(d,1) makes observation entries O(10..1000): mixed abs/rel
         worst["obs"] = max(worst["obs"], float((np.abs(o - ref["obs"]) / (1.0 + np.abs(ref["obs"])))[ok].max()))
@@ -35,7 +37,27 @@ def run(B, N, M, coop, box, steps, seed, dim=2):
           f"max|terms|={worst['terms']:.2e} covered mismatches={bad_cov} knife-edge envs skipped={skipped}/{total}", flush=True)
     assert worst["obs"] < 1e-5 and worst["rew"] < 1e-5 and worst["terms"] < 1e-5 and bad_cov == 0
 
+def fuzz(n_cases, seed):
+    """Random shapes / boxes / modes through the same comparison: odd and even N and M, one UAV, one target,
+    more than 32 and 64 targets (multi-word coverage masks), N past a wavefront, tiny and huge boxes, 2-D and 3-D."""
+    rng = np.random.RandomState(seed)
+    for c in range(n_cases):
+        N = int(rng.choice([1, 2, 3, 5, 7, 8, 11, 16, 19, 20, 21, 31, 32, 33, 47, 50, 63, 64, 65, 96, 127]))
+        M = int(rng.choice([1, 2, 3, 4, 9, 10, 17, 25, 31, 32, 33, 40, 63, 64, 65, 70]))
+        B = int(rng.choice([1, 2, 3, 17, 64, 100, 257]))
+        if N * B > 12000:
+            B = max(1, 12000 // N)
+        coop = float(rng.choice([0.0, 0.3, 0.9]))
+        box = float(rng.choice([50.0, 300.0, 1000.0, 2000.0, 10000.0]))
+        dim = int(rng.choice([2, 2, 3]))
+        run(B, N, M, coop, box, int(rng.choice([3, 8, 20])), 1000 + c, dim=dim)
+
+
 t0 = time.time()
+if "--fuzz" in sys.argv:
+    fuzz(int(sys.argv[sys.argv.index("--fuzz") + 1]), 7)
+    print(f"fuzz ok in {time.time()-t0:.0f} s")
+    sys.exit(0)
 if "--quick" not in sys.argv:
     run(4096, 20, 10, 0.0, 2000.0, 200, 1)
     run(4096, 20, 10, 0.3, 2000.0, 100, 2)

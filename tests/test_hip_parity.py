@@ -70,7 +70,7 @@ CASES = [
     # (N, M, cooperative, B)          specialised kernels: (5,3) (10,10) (20,10) (50,25); others generic
     (5, 3, 0.0, 200), (10, 10, 0.3, 150), (20, 10, 0.0, 256), (20, 10, 0.3, 256),
     (50, 25, 0.0, 64), (50, 25, 0.3, 64), (7, 4, 0.3, 99), (33, 40, 0.0, 31), (64, 1, 0.3, 9), (1, 5, 0.3, 70),
-    (130, 70, 0.3, 5),
+    (130, 70, 0.3, 5), (1, 70, 0.3, 300), (2, 65, 0.0, 90),     # few UAVs, many targets: LDS caps the envs per workgroup
 ]
 
 
