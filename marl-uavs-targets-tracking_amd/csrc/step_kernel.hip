@@ -563,9 +563,13 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         unsigned long long nbmask = 0;
         if (active) {
             Acc acc;
-            // weight of uav.py:165 can be < 1 only near the origin; wave-uniform branch
+            // weight of uav.py:165 can be < 1 only near the origin (|rel| <= 1, so |abs| < 2 is necessary).  The branch
+            // is per lane, not per wavefront: a lane's result must depend on its own environment only -- with a
+            // wave-uniform branch the (differently rounded) literal path would also be taken by whichever other
+            // environments happen to share the wavefront, and a shard of a batch would no longer reproduce the
+            // unsharded batch bit for bit.  Wavefronts that hold such a UAV (rare) run both paths.
             const bool near0 = fabsf(x) < 2.5f && fabsf(y) < 2.5f;
-            if (__builtin_expect(__any(near0), 0)) {
+            if (__builtin_expect(near0, 0)) {
                 sweep_weighted<Z3>(p, N, M, i, rowNew, rowOld, tenv, tzrow, covw, cbuf + e * CW,
                                    x, y, z, c, s, ai, acc);
                 if (kMask)

@@ -229,7 +229,7 @@ def greedy_actions(env: "OracleEnv", seed: int, step_count, env_offset: int = 0)
     B, N = cfg.n_envs, cfg.n_uav
     sc = np.ascontiguousarray(np.asarray(step_count, dtype=np.int32).reshape(B))
     act = np.empty((B, N), dtype=np.int32)
-    ms, ma, md = np.empty(B), np.empty(B), np.empty(B)
+    ms, ma, md = np.empty((B, N)), np.empty((B, N)), np.empty(B)      # per-UAV score / angle margins, per-env |d - dc|
     c = cfg.c_struct()
     rc = lib().orc_greedy_actions(C.byref(c), C.c_uint64(seed), C.c_int64(env_offset), _ip(sc),
                                   _dp(env.ux), _dp(env.uy), _dp(env.uh), _dp(env.tx), _dp(env.ty),

@@ -496,13 +496,16 @@ int orc_greedy_actions(const orc_config *cfg, uint64_t seed, int64_t env_offset,
         const double *x = ux + (size_t)b * N, *y = uy + (size_t)b * N, *h = uh + (size_t)b * N;
         const double *gx = tx + (size_t)b * M, *gy = ty + (size_t)b * M;
         const uint64_t gid = (uint64_t)(env_offset + b);
-        double ms = INFINITY, ma = INFINITY, md = INFINITY;
+        double md = INFINITY;
         int i, j, k, a;
         for (i = 0; i < N; ++i) {
             uint32_t ctr[4] = {(uint32_t)gid, (uint32_t)step_count[b], (uint32_t)i, 0x47524459u ^ (uint32_t)(gid >> 32)};
             uint32_t r[4];
             double best = -INFINITY, second = -INFINITY, best_angle = 0.0;
+            double ms = INFINITY, ma = INFINITY;                    /* this UAV's margins */
             orc_philox4x32_10(ctr, key, r);
+            if (mg_score) mg_score[(size_t)b * N + i] = INFINITY;
+            if (mg_angle) mg_angle[(size_t)b * N + i] = INFINITY;
             if (u01f(r[0]) < 0.25f) {                               /* uav.py:338-339 */
                 actions[(size_t)b * N + i] = (int32_t)(((uint64_t)r[1] * (uint32_t)na) >> 32);
                 continue;
@@ -543,9 +546,9 @@ int orc_greedy_actions(const orc_config *cfg, uint64_t seed, int64_t env_offset,
                 if (!straight && (secondd - bestd) * 0.5 < ma) ma = (secondd - bestd) * 0.5;
                 actions[(size_t)b * N + i] = besta;
             }
+            if (mg_score) mg_score[(size_t)b * N + i] = ms;
+            if (mg_angle) mg_angle[(size_t)b * N + i] = ma;
         }
-        if (mg_score) mg_score[b] = ms;
-        if (mg_angle) mg_angle[b] = ma;
         if (mg_dist) mg_dist[b] = md;
     }
     return 0;

@@ -490,7 +490,8 @@ def test_greedy_baseline_policy_vs_oracle(uavtrack):
             inject(orc, st)
             got = env.greedy_actions(seed=99).cpu().numpy()
             want, mg = greedy_actions(orc, 99, st["step_count"], env_offset=77)
-            ok = (mg["score"] > 1e-6) & (mg["angle"] > 1e-4) & (mg["dist"] > 1e-2)
+            # (the score 1/d - 0.8 * #others reaches tens in a crowded box, where an fp32 ulp is ~4e-6)
+            ok = (mg["score"] > 2e-5) & (mg["angle"] > 1e-4) & (mg["dist"][:, None] > 1e-2)
             assert ok.mean() > 0.5, (N, M, t, ok.mean())
             np.testing.assert_array_equal(got[ok], want[ok], err_msg=f"N{N} M{M} t{t}")
             assert got.min() >= 0 and got.max() <= 11
