@@ -40,9 +40,16 @@ def case(c, rng):
     H = int(rng.choice([64, 128]))
     T = int(rng.choice([1, 2, 7, 13]))
     off = int(rng.choice([0, 5, 10 ** 10]))
-    tag = f"case {c}: N{N} M{M} B{B} box{box} mode{mode} H{H} T{T} off{off}"
+    dim = int(rng.choice([2, 2, 2, 3]))
+    wgs = int(rng.choice([0, 0, 64, 128, 256, 512]))          # 0: the library's own choice
+    if wgs:
+        os.environ["UAVTRACK_WGS"] = str(wgs)
+    else:
+        os.environ.pop("UAVTRACK_WGS", None)
+    na = 12 * (3 if dim == 3 else 1)
+    tag = f"case {c}: N{N} M{M} B{B} box{box} mode{mode} H{H} T{T} off{off} dim{dim} wgs{wgs}"
     kw = dict(n_envs=B, n_uav=N, m_targets=M, x_max=box, y_max=box, cooperative=0.0 if mode == 0 else 0.3,
-              reward_mode=uavtrack.RewardMode(mode), env_offset=off)
+              reward_mode=uavtrack.RewardMode(mode), env_offset=off, dim=dim, nc=3 if dim == 3 else 1, z_max=300.0)
     pmi_sd = random_pmi_state_dict(H, c)
     if mode == 2:
         os.environ["UAVTRACK_PMI_SCRATCH_MB"] = str(int(rng.choice([1, 8, 2048])))
@@ -54,7 +61,7 @@ def case(c, rng):
         return e
     a, b = make(), make()
     a.reset(seed=c); b.reset(seed=c)
-    acts = torch.from_numpy(rng.randint(0, 12, size=(T, B, N)).astype(np.int32)).cuda()
+    acts = torch.from_numpy(rng.randint(0, na, size=(T, B, N)).astype(np.int32)).cuda()
     # 1. fused == single steps
     fused = a.step_many(acts)
     ep = torch.zeros(B, 5, device="cuda")
@@ -65,12 +72,13 @@ def case(c, rng):
     equal_dicts(a.get_state(), b.get_state(), a.get_state().keys(), tag + " state")
     np.testing.assert_allclose(fused["ep_sums"].cpu().numpy(), ep.cpu().numpy(), rtol=1e-5, atol=1e-5, err_msg=tag)
     # 4. teacher-forced vs oracle (one more step from the current state)
-    orc = OracleEnv(OracleConfig(n_envs=B, n_uav=N, m_targets=M, x_max=box, y_max=box, cooperative=kw["cooperative"]), n_threads=8)
+    orc = OracleEnv(OracleConfig(n_envs=B, n_uav=N, m_targets=M, x_max=box, y_max=box, cooperative=kw["cooperative"],
+                                 dim=dim, nc=3 if dim == 3 else 1, z_max=300.0), n_threads=8)
     if mode == 2:
         orc.pmi = OraclePmi.from_state_dict(pmi_sd)
     st = host(a.get_state())
-    orc.set_state(st["ux"], st["uy"], st["uh"], st["ua"], st["tx"], st["ty"], st["th"])
-    act = rng.randint(0, 12, size=(B, N)).astype(np.int32)
+    orc.set_state(st["ux"], st["uy"], st["uh"], st["ua"], st["tx"], st["ty"], st["th"], uz=st.get("uz"), tz=st.get("tz"))
+    act = rng.randint(0, na, size=(B, N)).astype(np.int32)
     obs, rew, _ = a.step(torch.from_numpy(act))
     ref = orc.step(act)
     ok = ref["margin"] > 1e-3
@@ -80,7 +88,7 @@ def case(c, rng):
         assert err_o.max() < 1e-5 and err_r.max() < 2e-5, f"{tag}: oracle obs {err_o.max():.2e} reward {err_r.max():.2e}"
         assert np.array_equal(a.info["covered"].cpu().numpy()[ok], ref["covered"][ok]), tag
     # 2. greedy (planar, RAW / MEAN)
-    if mode != 2:
+    if mode != 2 and dim == 2:
         g1, g2 = make(), make()
         g1.reset(seed=c + 1); g2.reset(seed=c + 1)
         fused = g1.run_greedy(T, seed=9)
@@ -95,7 +103,9 @@ def case(c, rng):
                 assert np.array_equal(ga.cpu().numpy()[okg], want[okg]), f"{tag}: greedy vs oracle"
             obs, rew, _ = g2.step(ga)
             assert torch.equal(obs, fused["obs"][t]) and torch.equal(rew, fused["reward"][t]), f"{tag}: run_greedy t{t}"
-    # 3. actor (all modes)
+    # 3. actor (all modes, planar action space)
+    if dim == 3:
+        return shard_check(c, rng, make, acts, B, off, tag, [a, b])
     torch.manual_seed(c)
     actor = uavtrack.ActorMLP(hidden_dim=int(rng.choice([16, 40, 128, 200])), action_dim=12)
     with torch.no_grad():
@@ -117,6 +127,10 @@ def case(c, rng):
         o, rew, _ = r2.step(aa)
         obs = o.clone()
         assert torch.equal(obs, fused["obs"][t]) and torch.equal(rew, fused["reward"][t]), f"{tag}: run_actor t{t}"
+    shard_check(c, rng, make, acts, B, off, tag, [a, b, r1, r2])
+
+
+def shard_check(c, rng, make, acts, B, off, tag, to_close):
     # 5. shard == unsharded
     if B >= 3:
         lo, cnt = B // 3, B - B // 3 - 1
@@ -125,7 +139,7 @@ def case(c, rng):
         fo = full.step_many(acts)
         po = part.step_many(acts[:, lo:lo + cnt].contiguous())
         assert torch.equal(po["obs"], fo["obs"][:, lo:lo + cnt]) and torch.equal(po["reward"], fo["reward"][:, lo:lo + cnt]), f"{tag}: shard"
-    for e in (a, b, r1, r2):
+    for e in to_close:
         e.close()
     print(tag, "ok", flush=True)
 
