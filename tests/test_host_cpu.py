@@ -255,3 +255,20 @@ def test_c_abi_builds_from_plain_c_and_fails_loudly_without_gpu(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 3, (r.returncode, r.stderr)
     assert "no HIP device" in r.stderr and "no CPU fallback" in r.stderr
+
+
+def test_bench_launch_plan_and_cores():
+    """bench.launch_plan: at most `rollout` steps per launch, never across an episode end, sums to `steps`."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for steps, rollout, horizon, pos in ((2000, 200, 200, 0), (1000, 1, 200, 0), (950, 64, 200, 130), (7, 200, 200, 199)):
+        plan, end = bench.launch_plan(steps, rollout, horizon, pos)
+        assert sum(plan) == steps and max(plan) <= rollout and min(plan) >= 1
+        p = pos
+        for T in plan:
+            assert p + T <= horizon          # a launch never spans two episodes
+            p = (p + T) % horizon
+        assert end == p
+    assert 1 <= bench.host_cores() <= os.cpu_count()
