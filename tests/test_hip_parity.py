@@ -747,3 +747,22 @@ def test_create_destroy_does_not_leak_and_errors_are_reported(uavtrack, pmi_stat
                         "fc2.weight": torch.zeros(36, 8), "fc2.bias": torch.zeros(36)})
     with pytest.raises(RuntimeError, match="planar"):
         env3.greedy_actions()
+
+
+def test_closed_loop_device_actor_graph_eager_fused_agree(uavtrack):
+    """BatchedRollout with the library's actor: per-step launches under HIP-graph replay == eager == one fused
+    launch (run_fused) -- same actions, same observations, same episode sums."""
+    _, sd = golden_actor()
+    actor = uavtrack.ActorMLP(hidden_dim=128, action_dim=12)
+    actor.load_state_dict(sd)
+    cfg = uavtrack.EnvConfig(n_envs=96, n_uav=20, m_targets=10)
+    res = {}
+    for name in ("eager", "graph", "fused"):
+        env = uavtrack.BatchedUavEnv(cfg)
+        ro = uavtrack.BatchedRollout(env, actor, steps_per_graph=5, use_graph=(name == "graph"), seed=8, device_actor=True)
+        ro.reset(seed=3)
+        out = ro.run_fused(17) if name == "fused" else ro.run(17)
+        res[name] = (out["obs"][-1].clone() if name == "fused" else out["obs"].clone(), out["ep_sums"].clone())
+    assert torch.equal(res["eager"][0], res["graph"][0]) and torch.equal(res["eager"][1], res["graph"][1])
+    assert torch.equal(res["eager"][0], res["fused"][0])
+    np.testing.assert_allclose(res["fused"][1].cpu().numpy(), res["eager"][1].cpu().numpy(), rtol=1e-5, atol=1e-5)
