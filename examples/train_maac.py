@@ -9,6 +9,12 @@ launch of the library (uavtrack_run_actor), its [T,B,N] outputs go straight into
 update is the same rule on a sampled batch, and the new actor weights are re-uploaded (sync_actor).
 
     python examples/train_maac.py --envs 1024 --iters 40
+    python examples/train_maac.py --method maac-r --envs 1024 --iters 40     # reciprocal (PMI) reward, PMI net trained too
+
+--method maac-r is the paper's method (configs/MAAC-R.yaml): the reward of every step is mixed in-kernel with the
+neighbours' rewards, weighted by the PMI network's scores (uav.py:262-291); that network is trained alongside on
+(timestep, uav-pair) samples of the rollout's observations (PMINet.py:74-100, here uavtrack.sample_pmi_pairs +
+pmi_contrastive_loss on the device history) and its BatchNorm-folded weights are re-uploaded every iteration.
 """
 import argparse
 import os
@@ -61,15 +67,26 @@ def main(argv=None):
     ap.add_argument("--gamma", type=float, default=0.95)
     ap.add_argument("--actor-lr", type=float, default=1e-4)
     ap.add_argument("--critic-lr", type=float, default=5e-4)
-    ap.add_argument("--cooperative", type=float, default=0.0)
+    ap.add_argument("--method", choices=["maac", "maac-g", "maac-r"], default="maac")
+    ap.add_argument("--cooperative", type=float, default=None, help="default: 0 for maac, 0.3 for maac-g / maac-r")
+    ap.add_argument("--pmi-hidden", type=int, default=128)   # configs/MAAC-R.yaml:39
+    ap.add_argument("--pmi-b2", type=int, default=3000)      # PMINetwork b2_size (PMINet.py:21)
+    ap.add_argument("--pmi-batch", type=int, default=500)
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args(argv)
 
     dev = "cuda:0"
     torch.manual_seed(args.seed)
-    cfg = uavtrack.EnvConfig(n_envs=args.envs, n_uav=args.n_uav, m_targets=args.m_targets, cooperative=args.cooperative,
-                             horizon=args.steps)
+    coop = args.cooperative if args.cooperative is not None else (0.0 if args.method == "maac" else 0.3)
+    mode = {"maac": uavtrack.RewardMode.RAW, "maac-g": uavtrack.RewardMode.MEAN, "maac-r": uavtrack.RewardMode.PMI}[args.method]
+    cfg = uavtrack.EnvConfig(n_envs=args.envs, n_uav=args.n_uav, m_targets=args.m_targets, cooperative=coop,
+                             reward_mode=mode, horizon=args.steps)
     env = uavtrack.BatchedUavEnv(cfg, dev)
+    pmi = opt_p = None
+    if args.method == "maac-r":
+        pmi = uavtrack.make_pmi_net(args.pmi_hidden).to(dev)
+        opt_p = torch.optim.Adam(pmi.parameters(), lr=1e-3)          # PMINet.py:39
+        env.set_pmi(pmi.state_dict())
     actor = uavtrack.ActorMLP(hidden_dim=args.hidden, action_dim=cfg.na_total).to(dev)
     critic = ValueNet(hidden_dim=args.hidden).to(dev)
     opt_a = torch.optim.Adam(actor.parameters(), lr=args.actor_lr)
@@ -91,13 +108,22 @@ def main(argv=None):
         t_roll = time.perf_counter() - t0
         for _ in range(args.updates):
             la, lc = update(actor, critic, opt_a, opt_c, replay.sample(args.batch), args.gamma)
+        lp = float("nan")
+        if pmi is not None:                                           # PMINetwork.train_pmi on this rollout's observations
+            pmi.train()
+            sel, _, _ = uavtrack.sample_pmi_pairs(res["obs"], args.n_uav, args.pmi_b2)
+            for x12, x13 in uavtrack.pmi_batches(sel, args.pmi_batch):
+                loss = uavtrack.pmi_contrastive_loss(pmi(x12), pmi(x13))
+                opt_p.zero_grad(); loss.backward(); opt_p.step()
+                lp = float(loss.detach())
+            env.set_pmi(pmi.state_dict())                             # eval-mode (running-stat) BatchNorm is what gets folded
         rollout.sync_actor()                                          # new weights for the next rollout
         ep = res["ep_sums"]                                           # [B, 5]: sum_t mean_i reward, 3 terms, covered
         ret, cov = float(ep[:, 0].mean()), float(ep[:, 4].mean()) / args.steps
         history.append(ret)
         torch.cuda.synchronize()
         print(f"iter {it:3d}  episode return {ret:8.3f}  covered targets/step {cov:5.2f}  actor loss {la:+.4f}  "
-              f"critic loss {lc:.4f}  rollout {t_roll * 1e3:6.1f} ms ({per_iter / t_roll / 1e9:.2f} G agent-steps/s)  "
+              f"critic loss {lc:.4f}  pmi loss {lp:.4f}  rollout {t_roll * 1e3:6.1f} ms ({per_iter / t_roll / 1e9:.2f} G agent-steps/s)  "
               f"iteration {(time.perf_counter() - t0) * 1e3:6.1f} ms", flush=True)
     env.close()
     return history

@@ -43,3 +43,28 @@ def fold_pmi_state_dict(sd: Mapping[str, object], eps: float = BN_EPS) -> tuple:
     blob = np.concatenate([wc.ravel(), bc, wo.ravel(), bo, wb.ravel(), bb, w1.ravel(), b1, w2, b2])
     assert blob.size == pmi_blob_size(H)
     return np.ascontiguousarray(blob, dtype=np.float32), int(H)
+
+
+def make_pmi_net(hidden_dim: int = 128):
+    """A trainable network with the reference PMINetwork's architecture and parameter names (PMINet.py:20-62:
+    three branch Linear+BatchNorm1d+ReLU over x[0:5] / x[5:9] / x[9:12], concat, Linear(3H,H)+BN+ReLU, Linear(H,1)),
+    so state_dicts move freely between the two and `BatchedUavEnv.set_pmi(net.state_dict())` folds and uploads
+    it.  Training stays plain PyTorch (learner side); see examples/train_maac.py --method maac-r."""
+    import torch
+
+    class PmiNet(torch.nn.Module):
+        def __init__(self, H: int):
+            super().__init__()
+            self.fc_comm, self.bn_comm = torch.nn.Linear(5, H), torch.nn.BatchNorm1d(H)
+            self.fc_obs, self.bn_obs = torch.nn.Linear(4, H), torch.nn.BatchNorm1d(H)
+            self.fc_boundary_state, self.bn_boundary_state = torch.nn.Linear(3, H), torch.nn.BatchNorm1d(H)
+            self.fc1, self.bn1 = torch.nn.Linear(3 * H, H), torch.nn.BatchNorm1d(H)
+            self.fc2 = torch.nn.Linear(H, 1)
+
+        def forward(self, x):
+            relu = torch.relu
+            parts = (relu(self.bn_comm(self.fc_comm(x[:, 0:5]))), relu(self.bn_obs(self.fc_obs(x[:, 5:9]))),
+                     relu(self.bn_boundary_state(self.fc_boundary_state(x[:, 9:12]))))
+            return self.fc2(relu(self.bn1(self.fc1(torch.cat(parts, dim=1)))))
+
+    return PmiNet(hidden_dim)

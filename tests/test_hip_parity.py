@@ -703,6 +703,9 @@ def test_example_training_loop_runs(uavtrack):
     spec.loader.exec_module(mod)
     hist = mod.main(["--envs", "64", "--iters", "3", "--steps", "40", "--batch", "4096", "--updates", "2"])
     assert len(hist) == 3 and all(np.isfinite(h) for h in hist)
+    hist = mod.main(["--method", "maac-r", "--envs", "64", "--iters", "3", "--steps", "40", "--batch", "4096", "--updates", "2",
+                     "--pmi-b2", "600", "--pmi-batch", "200"])
+    assert len(hist) == 3 and all(np.isfinite(h) for h in hist)
 
 
 def test_create_destroy_does_not_leak_and_errors_are_reported(uavtrack, pmi_state_dict):

@@ -272,3 +272,38 @@ def test_bench_launch_plan_and_cores():
             p = (p + T) % horizon
         assert end == p
     assert 1 <= bench.host_cores() <= os.cpu_count()
+
+
+def test_pmi_net_is_state_dict_compatible_and_folds(pmi_state_dict):
+    """make_pmi_net: the reference PMINetwork's recorded state_dict (golden pmi_h128) loads strictly; its eval-mode
+    forward equals the BatchNorm-folded affine chain that set_pmi uploads (fold_pmi_state_dict)."""
+    import torch
+    from uavtrack import make_pmi_net
+    net = make_pmi_net(128)
+    sd = {k: (torch.as_tensor(np.asarray(v))) for k, v in pmi_state_dict.items()}
+    for bn in ("bn_comm", "bn_obs", "bn_boundary_state", "bn1"):
+        sd.setdefault(bn + ".num_batches_tracked", torch.tensor(0))
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    x = torch.randn(64, 12, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        want = net(x).double().numpy().ravel()
+    blob, H = fold_pmi_state_dict(net.state_dict())
+    assert H == 128
+    b = blob.astype(np.float64)
+    o = 0
+
+    def take(n):
+        nonlocal o
+        v = b[o:o + n]; o += n
+        return v
+    wc, bc = take(5 * H).reshape(5, H), take(H)
+    wo, bo = take(4 * H).reshape(4, H), take(H)
+    wb, bb = take(3 * H).reshape(3, H), take(H)
+    w1, b1 = take(3 * H * H).reshape(3 * H, H), take(H)
+    w2, b2 = take(H), take(1)
+    xn = x.double().numpy()
+    a = np.concatenate([np.maximum(xn[:, 0:5] @ wc + bc, 0), np.maximum(xn[:, 5:9] @ wo + bo, 0),
+                        np.maximum(xn[:, 9:12] @ wb + bb, 0)], axis=1)
+    got = np.maximum(a @ w1 + b1, 0) @ w2 + b2
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
