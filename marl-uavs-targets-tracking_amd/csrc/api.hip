@@ -128,13 +128,14 @@ void fold_constants(const uavtrack_config &c, StepParams &p, float *climb_c, flo
         const float kmin = fminf(p.dp2, fminf(p.dc2, p.two_dp2));
         int e = 0;
         std::frexp(kmin, &e);                       // kmin = m * 2^e, m in [0.5, 1): ulp = 2^(e - 24)
-        int k = 24 - e;
+        int k = 25 - e;                             // 2 / ulp: the strict form's smallest positive value is ulp/2 * S
         if (k < 0) k = 0;
         const float S = std::ldexp(1.0f, k);
         p.le_neg_scale = -S;
         p.le_dp2 = std::nextafterf(p.dp2, INFINITY) * S;
         p.le_dc2 = std::nextafterf(p.dc2, INFINITY) * S;
         p.le_two_dp2 = std::nextafterf(p.two_dp2, INFINITY) * S;
+        p.lt_dp2 = p.dp2 * S;
     }
     p.vratio = (float)(c.t_v_max / c.u_v_max);
     p.inv_na_total = (float)(1.0 / (double)(c.na * c.nc));

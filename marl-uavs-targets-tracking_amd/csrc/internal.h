@@ -81,6 +81,7 @@ struct StepParams {
     float turn_unit;             // dt * h_max / (na - 1)        (uav.py:81,96)
     float inv_dc, inv_dp, dp, dp2, dc2, two_dp2;
     float le_neg_scale, le_dp2, le_dc2, le_two_dp2;   // pk_le_mask: -S and nextafter(K) * S per threshold
+    float lt_dp2;                                     // strict form: K * S  (d2 < K)
     float vratio;                // target.v_max / uav.v_max      (uav.py:116)
     float inv_na_total;
     float exp_k0, exp_k1;        // exp((2dp-d)/(2dp)) = exp2(k0 - k1*d)   (uav.py:226)

@@ -146,6 +146,10 @@ __device__ __forceinline__ void sincos_any(float h, float *s, float *c)
 
 // ---- LDS table geometry (float4 units) --------------------------------------------------
 __device__ __host__ __forceinline__ int pairs_of(int n) { return (n + 1) >> 1; }
+// coverage words per environment: 12 target PAIRS per word (two interleaved base-4 digit strings of 12 digits each,
+// accumulated exactly in fp32 by the packed sweep: see sweep_fast)
+constexpr int kCovPairs = 12;
+__device__ __host__ __forceinline__ int cov_words(int m) { return (pairs_of(m) + kCovPairs - 1) / kCovPairs; }
 // env stride of the UAV table: pairs * 2 copies * 3 float4, plus one float4 when the stride would
 // be a multiple of 64 dwords (rows of different envs read by one lane group would share banks)
 __device__ __host__ __forceinline__ int ustride_of(int n)
@@ -196,7 +200,7 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
 
     // ---- targets: observe_target (<= dp), tracking reward (<= dp), coverage (< dp)
     v2f sx = splat(0.f), sy = splat(0.f), sc = splat(0.f), ss = splat(0.f), cnt = splat(0.f), trk = splat(0.f);
-    unsigned bits = 0;
+    v2f cov = splat(0.f);   // coverage (d < dp, strict) of the pair's two targets as base-4 digits: cov = 4 * cov + {0, 1}
 #pragma unroll UAVTRACK_UNROLL_T
     for (int kp = 0; kp < MP; ++kp) {
         const float4 q0 = trow[kp * 2], q1 = trow[kp * 2 + 1];
@@ -215,11 +219,11 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
         ss = pk_fma(mm, (v2f){q1.z, q1.w}, ss);
         cnt += mm;
         trk = pk_fma(mm, pk_fma(dist, splat(-p.inv_dp), splat(2.0f)), trk);   // 1 + (dp - d)/dp
-        const int k = 2 * kp;
-        bits |= (d2.x < p.dp2 ? (1u << (k & 31)) : 0u) | (d2.y < p.dp2 ? (2u << (k & 31)) : 0u);
-        if ((k & 31) == 30 || kp == MP - 1) {
-            if (bits) atomicOr(&covw[covbase + (k >> 5)], bits);
-            bits = 0;
+        cov = pk_fma(cov, splat(4.0f), pk_le_mask(d2, nscale, p.lt_dp2));
+        if (kp % kCovPairs == kCovPairs - 1 || kp == MP - 1) {       // 12 digits < 2^24: exact in fp32
+            const unsigned bits = (unsigned)cov.x | ((unsigned)cov.y << 1);
+            if (bits) atomicOr(&covw[covbase + kp / kCovPairs], bits);
+            cov = splat(0.f);
         }
     }
     a.cntT = cnt.x + cnt.y; a.iwT = a.cntT;
@@ -312,10 +316,14 @@ __device__ __forceinline__ void sweep_weighted(const StepParams &p, int N, int M
         a.sxT = fmaf(iw, dx, a.sxT);
         a.syT = fmaf(iw, dy, a.syT);
         a.trk = fmaf(m, fmaf(-d, p.inv_dp, 2.0f), a.trk);
-        bits |= (d2 < p.dp2) ? (1u << (k & 31)) : 0u;
-        if ((k & 31) == 31 || k == M - 1) {
-            if (bits) atomicOr(&covw[covbase + (k >> 5)], bits);
-            bits = 0;
+        {   // the bit sweep_fast gives this target: digit (pairs in the word - 1 - pair index), slot k & 1
+            const int kp = k >> 1, word = kp / kCovPairs, MPw = pairs_of(M);
+            const int in_word = min(kCovPairs, MPw - word * kCovPairs);
+            bits |= (d2 < p.dp2) ? (1u << (2 * (in_word - 1 - kp % kCovPairs) + (k & 1))) : 0u;
+            if ((kp % kCovPairs == kCovPairs - 1 && (k & 1)) || k == M - 1) {
+                if (bits) atomicOr(&covw[covbase + word], bits);
+                bits = 0;
+            }
         }
     }
 #pragma unroll 1
@@ -357,7 +365,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     const int M = M_ > 0 ? M_ : p.M;
     const int E = p.E;
     const int EN = E * N;
-    const int CW = (M + 31) >> 5;
+    const int CW = cov_words(M);
     const int MP = pairs_of(M);
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;
@@ -772,7 +780,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
 
 size_t lds_bytes_for(int E, int N, int M, bool z3)
 {
-    const size_t CW = (M + 31) / 32, MP = pairs_of(M);
+    const size_t CW = cov_words(M), MP = pairs_of(M);
     const size_t f4 = (size_t)E * ustride_of(N) + (size_t)E * tstride_of(M);
     const size_t f = (size_t)E * M + (size_t)E * (N + 1) + (z3 ? (size_t)E * MP * 2 : 0) + (size_t)E * M + 2 * E * CW + 2;
     return (f4 * 16 + f * 4 + 15) & ~(size_t)15;   // ustride >= 3 N float4 per env, so ep_sums staging (E N float4) fits
