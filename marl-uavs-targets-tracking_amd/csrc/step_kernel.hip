@@ -236,6 +236,8 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
     //      sequential view (<= dc)
     sx = splat(0.f); sy = splat(0.f); sc = splat(0.f); ss = splat(0.f); cnt = splat(0.f);
     v2f sa = splat(0.f), dup = splat(0.f);
+    constexpr bool NBF = NB && N_ > 0 && (N_ + 1) / 2 <= kCovPairs;
+    v2f nbf = splat(0.f);
 #pragma unroll UU
     for (int jp = 0; jp < NP; ++jp) {
         const float4 *rs = (2 * jp < i) ? rowNew : rowOld;   // one select serves pose, heading, action, z
@@ -250,7 +252,9 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
             d2n = pk_fma(dzn, dzn, d2n);
             d2m = pk_fma(dzm, dzm, d2m);
         }
-        if (NB)   // MAAC-R (N <= 64): neighbours (d <= dp on post-move poses, uav.py:278) as a bit mask
+        if (NBF)       // <= 12 pairs: the same packed mask + base-4 digits as the coverage bits (bit order fixed up below)
+            nbf = pk_fma(nbf, splat(4.0f), pk_le_mask(d2n, nscale, p.le_dp2));
+        else if (NB)   // cooperative modes (N <= 64): neighbours (d <= dp on post-move poses, uav.py:278) as a bit mask
             nbmask |= ((unsigned long long)(d2n.x <= p.dp2 ? 1u : 0u) | (unsigned long long)(d2n.y <= p.dp2 ? 2u : 0u)) << (2 * jp);
         const v2f w = pk_fma((v2f){fast_sqrt(d2n.x), fast_sqrt(d2n.y)}, splat(-p.exp_k1), splat(p.exp_k0));
 #if UAVTRACK_LE_ASM
@@ -266,6 +270,10 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
         ss = pk_fma(mm, (v2f){m1.z, m1.w}, ss);
         sa = pk_fma(mm, (v2f){m2.x, m2.y}, sa);
         cnt += mm;
+    }
+    if (NBF) {   // Horner left pair jp at digit NP-1-jp: slot 1 into the even bits, reverse, align -> bit j = UAV j
+        const unsigned w = (unsigned)nbf.y | ((unsigned)nbf.x << 1);
+        nbmask = (unsigned long long)(__brev(w) >> (32 - 2 * NP));
     }
     // ---- self terms.  Post-move table: distance 0, exp2(k0).  Sequential view: odd i shares its pair
     //      with j = i - 1 < i, so it saw its own post-move pose (d = 0); even i saw its own pre-move pose.
