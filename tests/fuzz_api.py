@@ -46,10 +46,11 @@ def case(c, rng):
         os.environ["UAVTRACK_WGS"] = str(wgs)
     else:
         os.environ.pop("UAVTRACK_WGS", None)
-    na = 12 * (3 if dim == 3 else 1)
-    tag = f"case {c}: N{N} M{M} B{B} box{box} mode{mode} H{H} T{T} off{off} dim{dim} wgs{wgs}"
+    na_turn = int(rng.choice([12, 12, 12, 4, 7, 9]))        # environment.na (reference: 12)
+    na = na_turn * (3 if dim == 3 else 1)
+    tag = f"case {c}: N{N} M{M} B{B} box{box} mode{mode} H{H} T{T} off{off} dim{dim} wgs{wgs} na{na_turn}"
     kw = dict(n_envs=B, n_uav=N, m_targets=M, x_max=box, y_max=box, cooperative=0.0 if mode == 0 else 0.3,
-              reward_mode=uavtrack.RewardMode(mode), env_offset=off, dim=dim, nc=3 if dim == 3 else 1, z_max=300.0)
+              reward_mode=uavtrack.RewardMode(mode), env_offset=off, dim=dim, nc=3 if dim == 3 else 1, z_max=300.0, na=na_turn)
     pmi_sd = random_pmi_state_dict(H, c)
     if mode == 2:
         os.environ["UAVTRACK_PMI_SCRATCH_MB"] = str(int(rng.choice([1, 8, 2048])))
@@ -73,7 +74,7 @@ def case(c, rng):
     np.testing.assert_allclose(fused["ep_sums"].cpu().numpy(), ep.cpu().numpy(), rtol=1e-5, atol=1e-5, err_msg=tag)
     # 4. teacher-forced vs oracle (one more step from the current state)
     orc = OracleEnv(OracleConfig(n_envs=B, n_uav=N, m_targets=M, x_max=box, y_max=box, cooperative=kw["cooperative"],
-                                 dim=dim, nc=3 if dim == 3 else 1, z_max=300.0), n_threads=8)
+                                 dim=dim, nc=3 if dim == 3 else 1, z_max=300.0, na=na_turn), n_threads=8)
     if mode == 2:
         orc.pmi = OraclePmi.from_state_dict(pmi_sd)
     st = host(a.get_state())
@@ -107,7 +108,7 @@ def case(c, rng):
     if dim == 3:
         return shard_check(c, rng, make, acts, B, off, tag, [a, b])
     torch.manual_seed(c)
-    actor = uavtrack.ActorMLP(hidden_dim=int(rng.choice([16, 40, 128, 200])), action_dim=12)
+    actor = uavtrack.ActorMLP(hidden_dim=int(rng.choice([16, 40, 128, 200])), action_dim=na_turn)
     with torch.no_grad():
         actor.fc2.weight.mul_(5.0)
     r1, r2 = make(), make()
@@ -119,7 +120,7 @@ def case(c, rng):
         aa, probs = r2.actor_actions(obs, seed=4, want_probs=True)
         assert torch.equal(aa, fused["actions"][t]), f"{tag}: actor actions t{t}"
         if t == 0:
-            want, wp, mg = actor_actions(OracleConfig(n_envs=B, n_uav=N, m_targets=M), obs.cpu().numpy(), actor.state_dict(), 4,
+            want, wp, mg = actor_actions(OracleConfig(n_envs=B, n_uav=N, m_targets=M, na=na_turn), obs.cpu().numpy(), actor.state_dict(), 4,
                                          r2.get_state()["step_count"].cpu().numpy(), env_offset=off)
             assert np.abs(probs.cpu().numpy() - wp).max() < 1e-5, f"{tag}: actor probs"
             oka = mg > 1e-5
