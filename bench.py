@@ -372,9 +372,9 @@ def main():
             except Exception:
                 pass
         if args.policy == "actor":
-            # the actor adds 2*(12*H + H*16) fp32 MFMA flops per agent-step (actions padded to a 16-row tile)
+            # the actor adds 2*(12*H + H*16*tiles) fp32 MFMA flops per agent-step (actions padded to 16-row tiles: 1 in 2-D, 3 in 3-D)
             Hp = (args.actor_hidden + 15) // 16 * 16
-            line["roofline"]["actor_mfma_flop_per_agent_step"] = 2 * (12 * Hp + Hp * 16)
+            line["roofline"]["actor_mfma_flop_per_agent_step"] = 2 * (12 * Hp + Hp * 16 * (3 if args.dim == 3 else 1))
             line["roofline"]["actor_mfma_tflops"] = line["roofline"]["actor_mfma_flop_per_agent_step"] * avg_units / (avg_launch_ms * 1e-3) / 1e12
             line["roofline"]["note"] = ("closed-loop launch: environment step (HBM roofline above) plus the policy network on the "
                                         "fp32 matrix cores (peak 157.3 TFLOP/s); both figures are over the whole launch")
@@ -407,7 +407,7 @@ def main():
             torch.manual_seed(args.seed)
             actor = uavtrack.ActorMLP(hidden_dim=128, action_dim=12 * (3 if args.dim == 3 else 1)).to(device)
             cl = {}
-            modes = ("eager", "graph") + (("actor_graph", "greedy_graph") if args.dim == 2 else ())
+            modes = ("eager", "graph", "actor_graph") + (("greedy_graph",) if args.dim == 2 else ())
             for mode in modes:
                 env = make_env(uavtrack, args, B, device)
                 ro = uavtrack.BatchedRollout(env, "greedy" if mode == "greedy_graph" else actor, steps_per_graph=10,
@@ -434,6 +434,7 @@ def main():
                 dt = time.perf_counter() - t0
                 cl["greedy_fused"] = {"agent_steps_per_s": B * N * 1000 / dt, "ms_per_step": dt * 1e3 / 1000}
                 env.close()
+            for _once in (0,):
                 # actor + environment of a whole 200-step episode in one launch (uavtrack_run_actor)
                 env = make_env(uavtrack, args, B, device)
                 env.set_actor(actor)

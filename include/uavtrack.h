@@ -179,8 +179,9 @@ enum { UAVTRACK_ACTOR_SAMPLE = 0,   /* Categorical(probs).sample(): inverse CDF 
        UAVTRACK_ACTOR_ARGMAX = 1 }; /* deterministic evaluation: most probable action, lowest index on ties */
 
 /* Uploads FnnPolicyNet's parameters (HOST pointers, fp32, torch layouts): w1 [hidden][12] = fc1.weight,
- * b1 [hidden] = fc1.bias, w2 [na*nc][hidden] = fc2.weight, b2 [na*nc] = fc2.bias.  na*nc <= 12 (the
- * reference's action space, configs: na = 12).  w1 = NULL removes the actor.  Synchronises `stream`. */
+ * b1 [hidden] = fc1.bias, w2 [na*nc][hidden] = fc2.weight, b2 [na*nc] = fc2.bias.  na <= 12 in 2-D (the
+ * reference's action space, configs: na = 12), na*nc <= 48 in 3-D.  w1 = NULL removes the actor.
+ * Synchronises `stream`. */
 int uavtrack_set_actor_weights(uavtrack_env *env, const float *w1, const float *b1,
                                const float *w2, const float *b2, int32_t hidden, void *stream);
 

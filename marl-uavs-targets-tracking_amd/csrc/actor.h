@@ -35,22 +35,29 @@
 
 namespace uavtrack {
 
-constexpr int kActorMaxActions = 12;                  // the reference's action space (configs: na = 12)
 constexpr int kActorObs = UAVTRACK_OBS_DIM;            // 12
-constexpr int kActorFragsPerBlock = 11;
 constexpr int kActorLdsFloats = 64 * 20;               // per wavefront: logits at a 20-float stride (conflict-free b128)
+// Action tiles of 16 rows in the second GEMM: MT = 1 serves the reference's action space (na = 12), MT = 3 the
+// 3-D action space of our own spec (na * nc = 36, up to 48).  Per-lane softmax slots: 12 / 48.
+constexpr int actor_tiles(bool z3) { return z3 ? 3 : 1; }
+constexpr int actor_slots(int mt) { return mt == 1 ? 12 : 16 * mt; }
+constexpr int actor_frags_per_block(int mt) { return 7 + 4 * mt; }   // W1 x3, b1 x4, W2 x4 per tile
 
 typedef float actor_v4 __attribute__((ext_vector_type(4)));
 
 inline int actor_blocks(int hidden) { return (hidden + 15) / 16; }
-inline size_t actor_blob_floats(int hidden) { return ((size_t)actor_blocks(hidden) * kActorFragsPerBlock + 4) * 64; }
-
-// Host side: torch layouts (w1 [H][12], b1 [H], w2 [A][H], b2 [A]) -> fragment order above.
-inline void pack_actor_blob(const float *w1, const float *b1, const float *w2, const float *b2, int H, int A, float *blob)
+inline size_t actor_blob_floats(int hidden, int mt)
 {
-    const int HB = actor_blocks(H);
+    return ((size_t)actor_blocks(hidden) * actor_frags_per_block(mt) + 4 * mt) * 64;
+}
+
+// Host side: torch layouts (w1 [H][12], b1 [H], w2 [A][H], b2 [A]) -> fragment order above (tile t of W2 / b2
+// holds actions 16t .. 16t+15; its fragments follow tile t-1's).
+inline void pack_actor_blob(const float *w1, const float *b1, const float *w2, const float *b2, int H, int A, int mt, float *blob)
+{
+    const int HB = actor_blocks(H), FB = actor_frags_per_block(mt);
     for (int a = 0; a < HB; ++a) {
-        float *blk = blob + (size_t)a * kActorFragsPerBlock * 64;
+        float *blk = blob + (size_t)a * FB * 64;
         for (int l = 0; l < 64; ++l) {
             const int j = l & 15, g = l >> 4;
             for (int s = 0; s < 3; ++s) {
@@ -60,16 +67,20 @@ inline void pack_actor_blob(const float *w1, const float *b1, const float *w2, c
             for (int v = 0; v < 4; ++v) {
                 const int u = 16 * a + 4 * g + v;
                 blk[(3 + v) * 64 + l] = u < H ? b1[u] : 0.0f;
-                blk[(7 + v) * 64 + l] = (u < H && j < A) ? w2[(size_t)j * H + u] : 0.0f;
+                for (int t = 0; t < mt; ++t) {
+                    const int act = 16 * t + j;
+                    blk[(7 + 4 * t + v) * 64 + l] = (u < H && act < A) ? w2[(size_t)act * H + u] : 0.0f;
+                }
             }
         }
     }
-    float *tail = blob + (size_t)HB * kActorFragsPerBlock * 64;
+    float *tail = blob + (size_t)HB * FB * 64;
     for (int l = 0; l < 64; ++l)
-        for (int v = 0; v < 4; ++v) {
-            const int act = 4 * (l >> 4) + v;
-            tail[v * 64 + l] = act < A ? b2[act] : 0.0f;
-        }
+        for (int t = 0; t < mt; ++t)
+            for (int v = 0; v < 4; ++v) {
+                const int act = 16 * t + 4 * (l >> 4) + v;
+                tail[(4 * t + v) * 64 + l] = act < A ? b2[act] : 0.0f;
+            }
 }
 
 // EVERY lane of the wavefront must reach this call together (MFMA ignores EXEC); lanes without a UAV pass
@@ -81,11 +92,12 @@ struct ActorRng {          // Philox block cache of one UAV (see the draw below)
     bool valid;
 };
 
-template <bool WANT_PROBS>
+template <bool WANT_PROBS, int MT>
 __device__ __forceinline__ int actor_pick(const float (&o)[kActorObs], float *lds, const float *__restrict__ weights,
                                           int HB, int A, uint64_t genv, uint32_t step, int i, uint32_t k0, uint32_t k1,
                                           int mode, float *probs, ActorRng &rng)
 {
+    constexpr int FB = actor_frags_per_block(MT), SLOTS = actor_slots(MT);
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     // ---- the 12 inputs of the 64 samples, regrouped into B fragments: lane l <- obs[16n + l%16][4s + l/16]
     {
@@ -103,19 +115,22 @@ __device__ __forceinline__ int actor_pick(const float (&o)[kActorObs], float *ld
         for (int s = 0; s < 3; ++s) xf[n][s] = lds[(16 * n + j) * kActorObs + 4 * s + g];
 
     const float *wl = weights + lane;
-    actor_v4 d2[4];
+    actor_v4 d2[MT][4];
     {
-        const float *t = wl + (size_t)HB * kActorFragsPerBlock * 64;
-        const actor_v4 b2f = {t[0], t[64], t[128], t[192]};
+        const float *t = wl + (size_t)HB * FB * 64;
 #pragma unroll
-        for (int n = 0; n < 4; ++n) d2[n] = b2f;
+        for (int mt = 0; mt < MT; ++mt) {
+            const actor_v4 b2f = {t[(4 * mt) * 64], t[(4 * mt + 1) * 64], t[(4 * mt + 2) * 64], t[(4 * mt + 3) * 64]};
+#pragma unroll
+            for (int n = 0; n < 4; ++n) d2[mt][n] = b2f;
+        }
     }
 #pragma unroll 2
     for (int a = 0; a < HB; ++a) {
-        const float *wa = wl + (size_t)a * kActorFragsPerBlock * 64;
-        float wf[kActorFragsPerBlock];
+        const float *wa = wl + (size_t)a * FB * 64;
+        float wf[FB];
 #pragma unroll
-        for (int f = 0; f < kActorFragsPerBlock; ++f) wf[f] = wa[f * 64];
+        for (int f = 0; f < FB; ++f) wf[f] = wa[f * 64];
         const actor_v4 b1f = {wf[3], wf[4], wf[5], wf[6]};
         actor_v4 d1[4];
 #pragma unroll
@@ -130,45 +145,57 @@ __device__ __forceinline__ int actor_pick(const float (&o)[kActorObs], float *ld
 #pragma unroll
             for (int v = 0; v < 4; ++v) d1[n][v] = __builtin_amdgcn_fmed3f(d1[n][v], 0.0f, 3.0e38f);
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) d2[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[7 + v], d1[n][v], d2[n], 0, 0, 0);
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    d2[mt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[7 + 4 * mt + v], d1[n][v], d2[mt][n], 0, 0, 0);
     }
-    // ---- logits back to their own lane: lane l holds actions 4*(l/16) .. +3 of samples 16n + l%16
-    __builtin_amdgcn_wave_barrier();
+    // ---- logits back to their own lane, one action tile at a time through the same 5 KB: lane l holds actions
+    //      16t + 4*(l/16) .. +3 of samples 16n + l%16
+    float lg[SLOTS];
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
-        *reinterpret_cast<float4 *>(lds + (16 * n + j) * 20 + 4 * g) = make_float4(d2[n][0], d2[n][1], d2[n][2], d2[n][3]);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    float lg[kActorMaxActions];
+    for (int mt = 0; mt < MT; ++mt) {
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int q = 0; q < kActorMaxActions / 4; ++q) {
-        const float4 v = *reinterpret_cast<const float4 *>(lds + lane * 20 + 4 * q);
-        lg[4 * q] = v.x; lg[4 * q + 1] = v.y; lg[4 * q + 2] = v.z; lg[4 * q + 3] = v.w;
+        for (int n = 0; n < 4; ++n)
+            *reinterpret_cast<float4 *>(lds + (16 * n + j) * 20 + 4 * g) =
+                make_float4(d2[mt][n][0], d2[mt][n][1], d2[mt][n][2], d2[mt][n][3]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        constexpr int Q = (MT == 1) ? 3 : 4;               // float4 per tile this lane needs (12 of 16 at MT = 1)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(lds + lane * 20 + 4 * q);
+            lg[16 * mt * (MT > 1) + 4 * q] = v.x; lg[16 * mt * (MT > 1) + 4 * q + 1] = v.y;
+            lg[16 * mt * (MT > 1) + 4 * q + 2] = v.z; lg[16 * mt * (MT > 1) + 4 * q + 3] = v.w;
+        }
     }
     __builtin_amdgcn_wave_barrier();                 // the next call's input staging must not overtake these reads
-    if (A < kActorMaxActions) {                      // uniform; the reference's na = 12 fills every slot
+    if (A < SLOTS) {                                 // uniform; the reference's na = 12 fills every slot of MT = 1
 #pragma unroll
-        for (int q = 0; q < kActorMaxActions; ++q) lg[q] = (q < A) ? lg[q] : -INFINITY;
+        for (int q = 0; q < SLOTS; ++q) lg[q] = (q < A) ? lg[q] : -INFINITY;
     }
     float m = lg[0];
 #pragma unroll
-    for (int q = 1; q < kActorMaxActions; ++q) m = fmaxf(m, lg[q]);
-    float ex[kActorMaxActions], S = 0.0f;
+    for (int q = 1; q < SLOTS; ++q) m = fmaxf(m, lg[q]);
+    float ex[SLOTS], S = 0.0f;
 #pragma unroll
-    for (int q = 0; q < kActorMaxActions; ++q) {
+    for (int q = 0; q < SLOTS; ++q) {
         ex[q] = __builtin_amdgcn_exp2f((lg[q] - m) * 1.44269504088896340736f);   // masked slots: exp2(-inf) = 0
         S += ex[q];
     }
     if (WANT_PROBS && probs) {
         const float inv = 1.0f / S;
-        for (int q = 0; q < A; ++q) probs[q] = ex[q] * inv;
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q)
+            if (q < A) probs[q] = ex[q] * inv;
     }
     if (mode == UAVTRACK_ACTOR_ARGMAX) {
         int am = 0;
 #pragma unroll
-        for (int q = kActorMaxActions - 1; q >= 0; --q) am = (lg[q] == m) ? q : am;   // lowest index on ties
+        for (int q = SLOTS - 1; q >= 0; --q) am = (lg[q] == m) ? q : am;   // lowest index on ties
         return am;
     }
     // One Philox block serves four consecutive steps (its four words): the generator is the costly part of
@@ -186,7 +213,7 @@ __device__ __forceinline__ int actor_pick(const float (&o)[kActorObs], float *ld
     float c = 0.0f;
     int pick = 0;
 #pragma unroll
-    for (int q = 0; q < kActorMaxActions; ++q) {
+    for (int q = 0; q < SLOTS; ++q) {
         c += ex[q];
         pick += (c <= target) ? 1 : 0;
     }

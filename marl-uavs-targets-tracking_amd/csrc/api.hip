@@ -480,13 +480,14 @@ int uavtrack_set_actor_weights(uavtrack_env *env, const float *w1, const float *
     }
     if (!b1 || !w2 || !b2) return fail("uavtrack_set_actor_weights: b1, w2 and b2 must not be null");
     const int A = env->cfg.na * env->cfg.nc;
-    if (A > 12)
-        return fail("uavtrack_set_actor_weights: na*nc = %d actions; the device actor is built for the reference's "
-                    "action space (<= %d)", A, 12);
+    const int mt = actor_tiles(env->cfg.dim == 3);
+    if (A > actor_slots(mt))
+        return fail("uavtrack_set_actor_weights: na*nc = %d actions; the device actor holds up to %d in %d-D "
+                    "(12 = the reference's action space; 48 for the 3-D action space)", A, actor_slots(mt), env->cfg.dim);
     if (hidden < 1 || hidden > 4096) return fail("uavtrack_set_actor_weights: hidden %d out of range [1, 4096]", hidden);
-    const size_t n = actor_blob_floats(hidden);
+    const size_t n = actor_blob_floats(hidden, mt);
     std::vector<float> blob(n, 0.0f);
-    pack_actor_blob(w1, b1, w2, b2, hidden, A, blob.data());
+    pack_actor_blob(w1, b1, w2, b2, hidden, A, mt, blob.data());
     if (env->actor_hidden != hidden) {
         if (env->actor_w) (void)hipFree(env->actor_w);
         env->actor_w = nullptr; env->actor_hidden = 0;

@@ -80,6 +80,7 @@ struct ActorParams {
 
 // one lane per UAV, 64 UAVs per wavefront (the MFMA tile), flat over (env, uav); whole wavefronts stay
 // in step through actor_pick, lanes past the end carry zeros
+template <int MT>
 __global__ void __launch_bounds__(256) actor_policy_kernel(const ActorParams p)
 {
     __shared__ float lds[4][kActorLdsFloats];
@@ -98,7 +99,7 @@ __global__ void __launch_bounds__(256) actor_policy_kernel(const ActorParams p)
     float *pr = (valid && p.probs) ? p.probs + g * p.A : nullptr;
     ActorRng rng;
     rng.valid = false; rng.block = 0;
-    const int act = actor_pick<true>(o, lds[threadIdx.x >> 6], p.weights, p.hblocks, p.A, (uint64_t)(p.env_offset + b),
+    const int act = actor_pick<true, MT>(o, lds[threadIdx.x >> 6], p.weights, p.hblocks, p.A, (uint64_t)(p.env_offset + b),
                                      (uint32_t)step, i, p.k0, p.k1, p.mode, pr, rng);
     if (valid) p.actions[g] = act;
 }
@@ -116,7 +117,10 @@ hipError_t launch_actor(const uavtrack_env *env, const float *obs, uint64_t seed
     p.env_offset = c.env_offset;
     p.k0 = (uint32_t)seed; p.k1 = (uint32_t)(seed >> 32);
     const size_t rows = (size_t)c.n_envs * c.n_uav;
-    hipLaunchKernelGGL(actor_policy_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, p);
+    if (actor_tiles(c.dim == 3) == 1)
+        hipLaunchKernelGGL(actor_policy_kernel<1>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL(actor_policy_kernel<3>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -503,7 +503,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         //      observation, still in registers -- no table, no barrier
         if (ACTOR) {     // whole wavefronts: the two layers run on the matrix cores (actor.h)
             float *alds = reinterpret_cast<float *>(reinterpret_cast<char *>(smem4) + p.actor_lds_off) + (tid >> 6) * kActorLdsFloats;
-            act = actor_pick<false>(o, alds, p.actor_w, p.actor_hblocks, p.na_total, (uint64_t)(p.env_offset + b),
+            act = actor_pick<false, actor_tiles(Z3)>(o, alds, p.actor_w, p.actor_hblocks, p.na_total, (uint64_t)(p.env_offset + b),
                                     (uint32_t)count, i, p.greedy_k0, p.greedy_k1, p.actor_mode, nullptr, arng);
             if (active && p.actions_out) p.actions_out[tg_off] = act;
         }
@@ -803,8 +803,15 @@ KernelFn pick_mode(int mode, bool z3, int policy)
         return mode == UAVTRACK_REWARD_MEAN ? rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, false, kPolicyGreedy>
                                             : rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, false, kPolicyGreedy>;
     }
-    if (policy == kPolicyActor) {    // na*nc <= 12: planar
-        switch (mode) {
+    if (policy == kPolicyActor) {
+        if (z3) {                    // na*nc <= 48 (three action tiles)
+            switch (mode) {
+            case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, true, kPolicyActor>;
+            case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, UAVTRACK_REWARD_PMI, true, kPolicyActor>;
+            default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, true, kPolicyActor>;
+            }
+        }
+        switch (mode) {              // na <= 12 (one action tile)
         case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, false, kPolicyActor>;
         case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, UAVTRACK_REWARD_PMI, false, kPolicyActor>;
         default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, false, kPolicyActor>;

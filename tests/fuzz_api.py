@@ -104,11 +104,9 @@ def case(c, rng):
                 assert np.array_equal(ga.cpu().numpy()[okg], want[okg]), f"{tag}: greedy vs oracle"
             obs, rew, _ = g2.step(ga)
             assert torch.equal(obs, fused["obs"][t]) and torch.equal(rew, fused["reward"][t]), f"{tag}: run_greedy t{t}"
-    # 3. actor (all modes, planar action space)
-    if dim == 3:
-        return shard_check(c, rng, make, acts, B, off, tag, [a, b])
+    # 3. actor (all modes; one action tile in 2-D, three in 3-D)
     torch.manual_seed(c)
-    actor = uavtrack.ActorMLP(hidden_dim=int(rng.choice([16, 40, 128, 200])), action_dim=na_turn)
+    actor = uavtrack.ActorMLP(hidden_dim=int(rng.choice([16, 40, 128, 200])), action_dim=na)
     with torch.no_grad():
         actor.fc2.weight.mul_(5.0)
     r1, r2 = make(), make()
@@ -120,7 +118,8 @@ def case(c, rng):
         aa, probs = r2.actor_actions(obs, seed=4, want_probs=True)
         assert torch.equal(aa, fused["actions"][t]), f"{tag}: actor actions t{t}"
         if t == 0:
-            want, wp, mg = actor_actions(OracleConfig(n_envs=B, n_uav=N, m_targets=M, na=na_turn), obs.cpu().numpy(), actor.state_dict(), 4,
+            want, wp, mg = actor_actions(OracleConfig(n_envs=B, n_uav=N, m_targets=M, na=na_turn, dim=dim, nc=3 if dim == 3 else 1),
+                                         obs.cpu().numpy(), actor.state_dict(), 4,
                                          r2.get_state()["step_count"].cpu().numpy(), env_offset=off)
             assert np.abs(probs.cpu().numpy() - wp).max() < 1e-5, f"{tag}: actor probs"
             oka = mg > 1e-5

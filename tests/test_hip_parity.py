@@ -744,10 +744,14 @@ def test_create_destroy_does_not_leak_and_errors_are_reported(uavtrack, pmi_stat
     with pytest.raises(ValueError, match="do not match"):
         env.set_actor({"fc1.weight": torch.zeros(8, 11), "fc1.bias": torch.zeros(8),
                        "fc2.weight": torch.zeros(12, 8), "fc2.bias": torch.zeros(12)})
-    env3 = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(n_envs=2, n_uav=4, m_targets=2, dim=3, nc=3, z_max=300.0))
-    with pytest.raises(RuntimeError, match="36 actions"):
+    env3 = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(n_envs=2, n_uav=4, m_targets=2, dim=3, nc=5, na=12, z_max=300.0))
+    with pytest.raises(RuntimeError, match="60 actions"):
         env3.set_actor({"fc1.weight": torch.zeros(8, 12), "fc1.bias": torch.zeros(8),
-                        "fc2.weight": torch.zeros(36, 8), "fc2.bias": torch.zeros(36)})
+                        "fc2.weight": torch.zeros(60, 8), "fc2.bias": torch.zeros(60)})
+    env2 = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(n_envs=2, n_uav=4, m_targets=2, na=13))
+    with pytest.raises(RuntimeError, match="13 actions"):
+        env2.set_actor({"fc1.weight": torch.zeros(8, 12), "fc1.bias": torch.zeros(8),
+                        "fc2.weight": torch.zeros(13, 8), "fc2.bias": torch.zeros(13)})
     with pytest.raises(RuntimeError, match="planar"):
         env3.greedy_actions()
 
@@ -769,3 +773,39 @@ def test_closed_loop_device_actor_graph_eager_fused_agree(uavtrack):
     assert torch.equal(res["eager"][0], res["graph"][0]) and torch.equal(res["eager"][1], res["graph"][1])
     assert torch.equal(res["eager"][0], res["fused"][0])
     np.testing.assert_allclose(res["fused"][1].cpu().numpy(), res["eager"][1].cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+
+@pytest.mark.parametrize("N,M,coop,nc,hidden", [(50, 25, 0.0, 3, 128), (9, 6, 0.3, 3, 40), (20, 10, 0.0, 4, 64)])
+def test_3d_device_actor_vs_oracle_and_fused(uavtrack, N, M, coop, nc, hidden):
+    """The 3-D action space (na * nc = 36 / 48 actions, three action tiles in the second GEMM): probabilities and
+    draws against the fp64 oracle, and the fused actor rollout == actor kernel + step, bitwise."""
+    from oracle import actor_actions
+    B, A = 40, 12 * nc
+    torch.manual_seed(N)
+    actor = uavtrack.ActorMLP(hidden_dim=hidden, action_dim=A)
+    with torch.no_grad():
+        actor.fc2.weight.mul_(5.0)
+    kw = dict(n_envs=B, n_uav=N, m_targets=M, cooperative=coop, dim=3, nc=nc, z_max=300.0, env_offset=3)
+    a, b = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(**kw)), uavtrack.BatchedUavEnv(uavtrack.EnvConfig(**kw))
+    a.set_actor(actor); b.set_actor(actor)
+    obs0 = a.reset(seed=2)
+    obs = b.reset(seed=2).clone()
+    for mode in (0, 1):
+        act, probs = b.actor_actions(obs, seed=6, mode=mode, want_probs=True)
+        want_a, want_p, mg = actor_actions(OracleConfig(n_envs=B, n_uav=N, m_targets=M, dim=3, nc=nc), obs.cpu().numpy(),
+                                           actor.state_dict(), 6, np.zeros(B, np.int32), mode=mode, env_offset=3)
+        assert probs.shape == (B, N, A)
+        np.testing.assert_allclose(probs.cpu().numpy(), want_p, rtol=0, atol=ATOL)
+        ok = mg > 1e-5
+        assert ok.mean() > 0.5
+        np.testing.assert_array_equal(act.cpu().numpy()[ok], want_a[ok])
+        assert int(act.max()) >= 12                         # climb actions are really used
+    T = 9
+    fused = a.run_actor(T, obs0, seed=6)
+    for t in range(T):
+        act = b.actor_actions(obs, seed=6)
+        assert torch.equal(act, fused["actions"][t]), t
+        o, rew, _ = b.step(act)
+        obs = o.clone()
+        assert torch.equal(obs, fused["obs"][t]) and torch.equal(rew, fused["reward"][t]), t
