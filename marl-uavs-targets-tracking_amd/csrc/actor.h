@@ -20,11 +20,12 @@
 // by scalar-cache bandwidth: 15.6 -> see DESIGN.md for the closed-loop numbers.
 //
 // Device weight blob (uavtrack_set_actor_weights packs it), in units of one fragment = 64 floats, lane
-// l at offset l; HB = ceil(H/16) blocks of 11 fragments, then 4 fragments of b2:
-//   block a:  W1 s=0..2 : W1[16a + l%16][4s + l/16]
-//             b1 v=0..3 : b1[16a + 4*(l/16) + v]
-//             W2 v=0..3 : W2[l%16][16a + 4*(l/16) + v]          (rows >= na*nc and units >= H are zero)
-//   tail:     b2 v=0..3 : b2[4*(l/16) + v]
+// l at offset l; MT action tiles of 16 rows (1 in 2-D, 3 for the 3-D action space); HB = ceil(H/16) blocks
+// of 7 + 4*MT fragments, then 4*MT fragments of b2:
+//   block a:  W1 s=0..2        : W1[16a + l%16][4s + l/16]
+//             b1 v=0..3        : b1[16a + 4*(l/16) + v]
+//             W2 tile t, v=0..3: W2[16t + l%16][16a + 4*(l/16) + v]   (rows >= na*nc and units >= H are zero)
+//   tail:     b2 tile t, v=0..3: b2[16t + 4*(l/16) + v]
 //
 // Sampling: torch's Categorical draws from torch's own generator, which has no place inside a kernel;
 // here the draw is the inverse CDF of the same probabilities at a Philox uniform keyed by
