@@ -9,7 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -ffp-contract=off
 for f in api reset_kernel pmi_kernel policy_kernel; do
   /opt/rocm/bin/hipcc $FLAGS $ALLFLAGS -c $SRC/$f.hip -o $OUT/obj_$NAME/$f.o &
 done
-/opt/rocm/bin/hipcc $FLAGS $ALLFLAGS -fno-convergent-functions -fno-slp-vectorize "$@" -c $SRC/step_kernel.hip -o $OUT/obj_$NAME/step_kernel.o
+/opt/rocm/bin/hipcc $FLAGS $ALLFLAGS -fno-convergent-functions -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -c $SRC/step_kernel.hip -o $OUT/obj_$NAME/step_kernel.o
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/$NAME.so $OUT/obj_$NAME/*.o
 echo built $OUT/$NAME.so
