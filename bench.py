@@ -9,18 +9,28 @@ At N = 1 the workload is BASELINE.json configs[1]: 4096 envs x 20 UAVs x 10 targ
 (weak scaling, configs[4]) and the only collective is the end-of-rollout all-gather of
 the per-env episode accumulators over RCCL.
 
-Timed region: K steps issued as fused rollouts of `--rollout` (default 200 = the
-reference horizon, main.py:128) steps per launch with pre-sampled int32 actions resident
-in HBM, a reset between rollouts, bracketed by barrier + synchronize, max
-over ranks.  Rank 0 prints ONE JSON line.  Extra keys on that line:
-  roofline      dominant kernel (rollout_kernel) vs the 8 TB/s HBM roof, algorithmic bytes
-  cpu_baseline  the C oracle (a port of the reference algorithm) timed on this host's cores
-  per_step_launch / saturating_batch   the same kernel launched one step at a time, and at a
-                batch large enough to fill the chip
+`--gpus N` with N > 1 starts the N ranks itself (one child process per GPU, spawned before
+the parent makes any GPU call; the parent only waits); under torchrun (WORLD_SIZE set) the
+process is a rank already.  If N ranks cannot be had the run exits non-zero -- it never
+degrades to fewer GPUs.
+
+Timed region (`value`, `ms_per_step`): EXACTLY K steps issued as fused rollouts of at most
+`--rollout` (default 200 = the reference horizon, main.py:128) steps per launch, never across
+an episode end, with pre-sampled int32 actions resident in HBM and a reset at
+every episode end, bracketed by barrier + synchronize, max over ranks.  `config.launch`
+names the launches that were really timed.
+
+`roofline` does not depend on K: rank 0 times a fixed leg of 200-step rollout launches
+(the reference horizon), all enqueued back to back before the first event is waited on, so host
+latency is off the clock; HIP events on the launch stream around every launch.
+`cpu_baseline` is the C oracle (a port of the reference algorithm) on this host's cores.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,6 +41,8 @@ for _p in (ROOT, os.path.join(ROOT, "marl-uavs-targets-tracking_amd")):
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_CEILING_GBS = 6290.0
+ROOFLINE_T = 200               # steps per launch of the roofline leg: the reference horizon (main.py:128)
+ROOFLINE_LAUNCHES = 6
 
 
 def algorithmic_bytes_per_agent_step(n_uav, m_targets, dim=2, terms=True):
@@ -42,7 +54,7 @@ def algorithmic_bytes_per_agent_step(n_uav, m_targets, dim=2, terms=True):
     return b + 24.0 * m_targets / n_uav
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -63,13 +75,83 @@ def parse():
                     help="side of the square field in metres (reference: 2000; 500 = the dense MAAC-R worst case of SURVEY 8d)")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip per-step-launch and saturating-batch legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip per-step-launch, saturating-batch and closed-loop legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only to rehearse "
                     "the multi-rank code path on a single GPU together with UAVTRACK_BENCH_ONE_GPU=1")
-    return ap.parse_args()
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="launcher check without a GPU: the ranks rendezvous, all-reduce one number and rank 0 prints a "
+                         "line with n_gpus / rccl_world_size (used by the CPU test of the --gpus N spawn path)")
+    return ap.parse_args(argv)
 
 
+# ---------------------------------------------------------------------------------------------
+# --gpus N: the launcher.  Runs in a parent that never touches the GPU.
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args, argv):
+    """Start args.gpus copies of this script, one per GPU, with the torchrun environment contract
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).  Rank 0 inherits stdout (its JSON line is
+    the run's output); the other ranks' stdout goes to stderr.  Returns the exit code for the parent."""
+    n = args.gpus
+    if not args.selftest_launcher and args.backend == "nccl" and os.environ.get("UAVTRACK_BENCH_ONE_GPU") != "1":
+        import torch                                  # device_count() does not initialise the GPU
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write(f"bench.py: --gpus {n} but only {have} GPU(s) are visible; refusing to run on fewer\n")
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    deadline = None
+    while procs:
+        for p in list(procs):
+            code = p.poll()
+            if code is None:
+                continue
+            procs.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                deadline = time.time() + 30          # a rank died: give the others a moment, then stop them
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                p.kill()
+        time.sleep(0.05)
+    if rc != 0:
+        sys.stderr.write(f"bench.py: a rank exited with code {rc}; --gpus {n} could not be honoured\n")
+    return rc
+
+
+def launcher_selftest(args, world, rank):
+    """No GPU: proves that the spawn path yields `world` ranks that can talk."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(args.backend if args.backend != "nccl" else "gloo")
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        assert int(t.item()) == world * (world + 1) // 2
+        ws = dist.get_world_size()
+    else:
+        ws = 1
+    if rank == 0:
+        print(json.dumps({"selftest": "launcher", "n_gpus": world, "rccl_world_size": ws, "gpus_requested": args.gpus}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------
 def synthetic_pmi_state_dict(hidden, seed=42):
     """Random-init PMINetwork-shaped weights (PMINet.py:29-38 shapes, torch default init ranges)
     with non-trivial BatchNorm statistics; there is no checkpoint to load."""
@@ -97,7 +179,7 @@ def make_env(uavtrack, args, B, device, env_offset=0):
     cfg = uavtrack.EnvConfig(n_envs=B, n_uav=args.n_uav, m_targets=args.m_targets, dim=args.dim,
                              x_max=getattr(args, "box", 2000.0), y_max=getattr(args, "box", 2000.0), nc=nc,
                              cooperative=args.cooperative, reward_mode=mode,
-                             horizon=args.rollout if args.rollout > 1 else 200, env_offset=env_offset)
+                             horizon=ROOFLINE_T, env_offset=env_offset)
     env = uavtrack.BatchedUavEnv(cfg, device)
     if args.reward == "pmi":
         env.set_pmi(synthetic_pmi_state_dict(args.pmi_hidden, 42))
@@ -118,6 +200,31 @@ def launch_plan(steps, rollout, horizon, ep_steps):
         steps -= T
         ep_steps = (ep_steps + T) % horizon
     return plan, ep_steps
+
+
+def describe_plan(plan):
+    """'3 x 200 + 1 x 20' -- the launches of a plan, in order, run-length encoded."""
+    runs = []
+    for T in plan:
+        if runs and runs[-1][1] == T:
+            runs[-1][0] += 1
+        else:
+            runs.append([1, T])
+    return " + ".join(f"{n} x {T}" for n, T in runs) + " steps"
+
+
+def alloc_outputs(args, B, T, device):
+    import torch
+    import uavtrack._lib as _l
+    out = dict(obs=torch.empty(T, B, args.n_uav, _l.OBS_DIM, device=device),
+               reward=torch.empty(T, B, args.n_uav, device=device),
+               terms=torch.empty(T, 3, B, args.n_uav, device=device),
+               covered=torch.empty(T, B, dtype=torch.int32, device=device),
+               done=torch.empty(T, B, dtype=torch.uint8, device=device),
+               ep_sums=torch.empty(B, 5, device=device))
+    if args.policy == "actor":
+        out["actions"] = torch.empty(T, B, args.n_uav, dtype=torch.int32, device=device)
+    return out
 
 
 def run_rollouts(env, actions, plan, ep_steps, out, events=None, gather=None, policy="given", obs=None):
@@ -150,34 +257,24 @@ def run_rollouts(env, actions, plan, ep_steps, out, events=None, gather=None, po
 
 
 def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, env_offset=0, total_envs=None):
+    """The contract's timed region: `warmup` untimed steps, then exactly `steps` steps between
+    barrier + synchronize.  Returns wall time, the plan that was timed and per-launch HIP-event times."""
     import torch
     env = make_env(uavtrack, args, B, device, env_offset)
     na_total = env.cfg.na_total
     g = torch.Generator(device=device).manual_seed(args.seed + env_offset)
-    rows = max(rollout, env.cfg.horizon)      # one pre-sampled action row per step of an episode
-    actions = torch.randint(0, na_total, (rows, B, args.n_uav), dtype=torch.int32, device=device, generator=g)
-    out = {}
+    horizon = env.cfg.horizon
+    actions = torch.randint(0, na_total, (horizon, B, args.n_uav), dtype=torch.int32, device=device, generator=g)
     gather = None
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
         # asynchronous: the collective runs on RCCL's stream from a private copy, the next rollout does not wait
         # for it (nor for a slower rank); every handle is waited on before the clock stops
         pending = []
         gather = lambda ep: pending.append(uavtrack.gather_rollout_summary_async(ep, n_envs_total=total_envs))
-    horizon = env.cfg.horizon
     warm_plan, pos = launch_plan(warmup, rollout, horizon, 0)
     timed_plan, _ = launch_plan(steps, rollout, horizon, pos)
-    # output buffers of every launch shape of the timed region exist before it starts (allocation is
-    # not part of a step)
-    import uavtrack._lib as _l
-    for T in set(timed_plan):
-        out[T] = dict(obs=torch.empty(T, B, args.n_uav, _l.OBS_DIM, device=device),
-                      reward=torch.empty(T, B, args.n_uav, device=device),
-                      terms=torch.empty(T, 3, B, args.n_uav, device=device),
-                      covered=torch.empty(T, B, dtype=torch.int32, device=device),
-                      done=torch.empty(T, B, dtype=torch.uint8, device=device),
-                      ep_sums=torch.empty(B, 5, device=device))
-        if args.policy == "actor":
-            out[T]["actions"] = torch.empty(T, B, args.n_uav, dtype=torch.int32, device=device)
+    # output buffers of every launch shape exist before the clock starts (allocation is not part of a step)
+    out = {T: alloc_outputs(args, B, T, device) for T in set(timed_plan) | set(warm_plan)}
     obs0 = env.reset(seed=args.seed)
     _, obs0 = run_rollouts(env, actions, warm_plan, 0, out, gather=gather, policy=args.policy, obs=obs0)
     if gather is not None:
@@ -188,7 +285,6 @@ def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, en
     if gather is not None:
         dist.barrier()
     events = []
-    pairs0 = env.pmi_pairs_scored() if args.reward == "pmi" else 0
     t0 = time.perf_counter()
     launches, _ = run_rollouts(env, actions, timed_plan, pos, out, events=events, gather=gather, policy=args.policy, obs=obs0)
     if gather is not None:
@@ -200,9 +296,44 @@ def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, en
     wall = time.perf_counter() - t0
     kern_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in events)
     info = env.kernel_info()
-    pairs = env.pmi_pairs_scored() - pairs0 if args.reward == "pmi" else 0
     env.close()
-    return dict(wall_s=wall, kernel_ms_total=kern_ms, launches=launches, steps=steps, geometry=info, pmi_pairs=pairs)
+    return dict(wall_s=wall, kernel_ms_total=kern_ms, launches=launches, steps=steps, geometry=info,
+                timed_plan=timed_plan, warm_plan=warm_plan)
+
+
+def roofline_leg(uavtrack, args, B, device, T=ROOFLINE_T, launches=ROOFLINE_LAUNCHES):
+    """`launches` rollout launches of T steps each (an episode: reset, then one launch), ALL enqueued before the
+    first event is waited on, a HIP event pair on the launch stream around every rollout launch (the resets lie
+    outside the pairs).  One untimed launch first.  Independent of --steps."""
+    import torch
+    env = make_env(uavtrack, args, B, device)
+    g = torch.Generator(device=device).manual_seed(args.seed)
+    actions = torch.randint(0, env.cfg.na_total, (T, B, args.n_uav), dtype=torch.int32, device=device, generator=g)
+    out = alloc_outputs(args, B, T, device)
+
+    def one(obs):
+        if args.policy == "actor":
+            return env.run_actor(T, obs, seed=42, out=out)
+        if args.policy == "greedy":
+            return env.run_greedy(T, seed=42)
+        return env.step_many(actions, out=out)
+    one(env.reset(seed=args.seed))
+    torch.cuda.synchronize(device)
+    pairs0 = env.pmi_pairs_scored() if args.reward == "pmi" else 0
+    pairs = []
+    for _ in range(launches):
+        obs = env.reset(seed=args.seed)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        one(obs)
+        e1.record()
+        pairs.append((e0, e1))
+    torch.cuda.synchronize(device)
+    ms = [e0.elapsed_time(e1) for e0, e1 in pairs]
+    pmi_pairs = env.pmi_pairs_scored() - pairs0 if args.reward == "pmi" else 0
+    info = env.kernel_info()
+    env.close()
+    return dict(T=T, launches=launches, ms=ms, avg_ms=sum(ms) / len(ms), pmi_pairs=pmi_pairs, geometry=info)
 
 
 def host_cores():
@@ -257,30 +388,136 @@ def cpu_baseline(args, seconds):
                 value_1core=v1, sample_1core=f"{B1} envs x {T} steps, 1 thread")
 
 
-def main():
-    args = parse()
+def lookup_traffic(B, N, M, T, args):
+    """HBM bytes per launch from the committed PMC profile of exactly this launch shape, else None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if args.reward != "raw" or args.dim != 2 or args.policy != "given" or not os.path.exists(path):
+        return None, None
+    try:
+        tr = json.load(open(path))
+    except Exception:
+        return None, None
+    ent = tr.get(f"{B}x{N}x{M}_T{T}")
+    if not ent:
+        return None, None
+    return ent["hbm_bytes_per_launch"], ent.get("source", "profiles/")
+
+
+def extras(uavtrack, args, B, device, bytes_unit):
+    """The same kernel in other regimes (N = 1, headline workload only): one launch per step, a chip-filling
+    batch, and the closed loops of SURVEY 8f-1 / 8f-2."""
+    import torch
+    N, M = args.n_uav, args.m_targets
+    out = {}
+    # one launch per env step (what a closed-loop policy would do eagerly); host-bound and noisy on a shared
+    # box (25 to 80 us per step for one binary within a minute): three short runs, the best one is reported
+    k = 400
+    runs = [time_config(uavtrack, args, B, k, 100, 1, device) for _ in range(3)]
+    r1 = min(runs, key=lambda r: r["wall_s"])
+    out["per_step_launch"] = {
+        "agent_steps_per_s": B * N * k / r1["wall_s"], "ms_per_step": r1["wall_s"] * 1e3 / k,
+        "kernel_ms_per_step": r1["kernel_ms_total"] / r1["launches"],
+        "ms_per_step_all_runs": [r["wall_s"] * 1e3 / k for r in runs],
+        "note": "uavtrack_step eager from Python/ctypes, best of three 400-step runs; host-launch bound",
+    }
+    # a batch that fills the chip (SURVEY 8d 'bandwidth-saturating batch'), measured like the roofline leg
+    Bs, Ts = 65536, 50
+    rs = roofline_leg(uavtrack, args, Bs, device, T=Ts, launches=4)
+    ach = bytes_unit * Bs * N * Ts / (rs["avg_ms"] * 1e-3) / 1e9
+    out["saturating_batch"] = {
+        "workload": f"{Bs} envs x {N} UAVs x {M} targets, {Ts} steps per launch",
+        "agent_steps_per_s": Bs * N * Ts / (rs["avg_ms"] * 1e-3),
+        "roofline_achieved_GBs": ach, "roofline_frac": ach / HBM_PEAK_GBS,
+        "avg_launch_ms": rs["avg_ms"], "geometry": rs["geometry"],
+    }
+    # closed loop (SURVEY 8f-1): actor forward [B*N,12] -> sample -> uavtrack_step per step, eager
+    # launches vs the same steps replayed from a HIP graph
+    torch.manual_seed(args.seed)
+    actor = uavtrack.ActorMLP(hidden_dim=128, action_dim=12 * (3 if args.dim == 3 else 1)).to(device)
+    cl = {}
+    modes = ("eager", "graph", "actor_graph") + (("greedy_graph",) if args.dim == 2 else ())
+    for mode in modes:
+        env = make_env(uavtrack, args, B, device)
+        ro = uavtrack.BatchedRollout(env, "greedy" if mode == "greedy_graph" else actor, steps_per_graph=10,
+                                     use_graph=(mode != "eager"), device_actor=(mode == "actor_graph"))
+        ro.reset(seed=args.seed)
+        ro.run(40)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        ro.run(400)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        cl[mode] = {"agent_steps_per_s": B * N * 400 / dt, "ms_per_step": dt * 1e3 / 400}
+        env.close()
+    if args.dim == 2:      # the same closed loop fused into one launch per 200-step episode
+        env = make_env(uavtrack, args, B, device)
+        env.reset(seed=args.seed)
+        env.run_greedy(200, seed=args.seed)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            env.reset(seed=args.seed)
+            env.run_greedy(200, seed=args.seed)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        cl["greedy_fused"] = {"agent_steps_per_s": B * N * 1000 / dt, "ms_per_step": dt * 1e3 / 1000}
+        env.close()
+    # actor + environment of a whole 200-step episode in one launch (uavtrack_run_actor)
+    env = make_env(uavtrack, args, B, device)
+    env.set_actor(actor)
+    res = env.run_actor(200, env.reset(seed=args.seed), seed=args.seed, want_terms=False)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        res = env.run_actor(200, env.reset(seed=args.seed), seed=args.seed, want_terms=False, out=res)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    cl["actor_fused"] = {"agent_steps_per_s": B * N * 1000 / dt, "ms_per_step": dt * 1e3 / 1000}
+    env.close()
+    cl["note"] = ("reference-shaped shared actor (FnnPolicyNet 12-128-12 softmax as in configs/MAAC.yaml, random "
+                  "init) + categorical sample + uavtrack_step_accumulate, all on device; eager/graph = the actor "
+                  "forward and the sample as PyTorch ops, graph = 10 steps per HIP-graph replay; actor_graph = the same "
+                  "with the library's own actor kernel (uavtrack_actor_actions); actor_fused = uavtrack_run_actor, "
+                  "actor and step of a whole 200-step episode in one launch (the rollout of train.operate_epoch); "
+                  "greedy_graph / greedy_fused = the same two forms with the reference's C-METHOD baseline policy "
+                  "(uav.py:324-369) instead of the actor")
+    out["closed_loop"] = cl
+    return out
+
+
+def worker(args):
+    """One rank.  WORLD_SIZE / RANK / LOCAL_RANK come from the launcher (spawn_ranks or torchrun)."""
     args.cooperative = 0.0 if args.reward == "raw" else 0.3       # configs/MAAC.yaml vs MAAC-G/MAAC-R.yaml
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; refusing to report a run of a different size\n")
+        sys.exit(2)
+    if args.selftest_launcher:
+        return launcher_selftest(args, world, rank)
+
     import torch
     import torch.distributed as dist
     import uavtrack
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("UAVTRACK_BENCH_ONE_GPU") == "1":
         local_rank = 0                      # rehearsal: every rank shares cuda:0 (gloo backend only)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-        else:
-            dist.init_process_group(args.backend)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the environment has no CPU path")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} has no GPU (LOCAL_RANK {local_rank}, {torch.cuda.device_count()} visible)")
     device = f"cuda:{local_rank}"
     torch.cuda.set_device(device)
+    rccl_world = 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(args.backend)
+        rccl_world = dist.get_world_size()
+        assert rccl_world == world
 
     B, N, M = args.envs, args.n_uav, args.m_targets
     res = time_config(uavtrack, args, B, args.steps, args.warmup, args.rollout, device,
@@ -292,17 +529,20 @@ def main():
 
     if rank == 0:
         bytes_unit = algorithmic_bytes_per_agent_step(N, M, args.dim)
-        agent_steps = world * B * N * args.steps
-        value = agent_steps / wall_s
-        units_per_launch = B * N * args.rollout
-        avg_launch_ms = res["kernel_ms_total"] / res["launches"]
-        avg_units = B * N * args.steps / res["launches"]
-        achieved = bytes_unit * avg_units / (avg_launch_ms * 1e-3) / 1e9
+        value = world * B * N * args.steps / wall_s
+        roof = roofline_leg(uavtrack, args, B, device)
+        units_per_launch = B * N * roof["T"]
+        achieved = bytes_unit * units_per_launch / (roof["avg_ms"] * 1e-3) / 1e9
+        traffic, traffic_src = lookup_traffic(B, N, M, roof["T"], args)
+        fn = {"given": "uavtrack_step_many", "greedy": "uavtrack_run_greedy", "actor": "uavtrack_run_actor"}[args.policy]
+        if args.rollout == 1 and args.policy == "given":
+            fn = "uavtrack_step"
         line = {
             "metric": "env agent-steps/sec",
             "value": value,
             "unit": "agent-steps/s",
             "n_gpus": world,
+            "rccl_world_size": rccl_world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": wall_s * 1e3 / args.steps,
@@ -318,10 +558,13 @@ def main():
                             + (f" (BASELINE configs[{4 if world > 1 else (3 if args.dim == 3 else {'raw': 1, 'mean': 1, 'pmi': 2}[args.reward])}])"),
                 "envs_total": world * B,
                 "box_m": args.box,
-                "launch": (f"{ {'given': 'uavtrack_step_many', 'greedy': 'uavtrack_run_greedy', 'actor': 'uavtrack_run_actor'}[args.policy] }, {args.rollout} steps per call, reset between rollouts"
-                           + ("; MAAC-R issues 3 kernels per step (fused step, MFMA pair scorer, softmax mix)"
-                              if args.reward == "pmi" else " (one kernel launch per call)"))
-                          if args.rollout > 1 else "uavtrack_step, one launch per step",
+                "step": "one Environment.step of every environment of the batch",
+                "launch": f"{fn}: {describe_plan(res['timed_plan'])} per call in the timed region "
+                          f"({len(res['timed_plan'])} launch{'es' if len(res['timed_plan']) != 1 else ''}; reset at every episode end, "
+                          f"horizon {ROOFLINE_T})"
+                          + ("; MAAC-R issues three kernels per chunk (fused step, MFMA pair scorer, softmax mix)" if args.reward == "pmi" else ""),
+                "timed_launch_steps": res["timed_plan"],
+                "warmup_launch_steps": res["warm_plan"],
                 "actions": {"given": "pre-sampled int32[T,B,N] uniform, seed 42, resident in HBM",
                             "greedy": "in-kernel C-METHOD baseline policy (uavtrack_run_greedy), closed loop",
                             "actor": f"in-kernel FnnPolicyNet 12-{args.actor_hidden}-{12 * (3 if args.dim == 3 else 1)} actor, random init, "
@@ -339,122 +582,44 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
-                "traffic": None,
+                "traffic": traffic,
                 "algorithmic_bytes_per_agent_step": bytes_unit,
-                "agent_steps_per_launch": avg_units,
-                "avg_launch_ms": avg_launch_ms,
-                "launches_timed": res["launches"],
-                "timing": "HIP events on the launch stream, around every rollout launch of the timed region",
+                "steps_per_launch": roof["T"],
+                "agent_steps_per_launch": units_per_launch,
+                "avg_launch_ms": roof["avg_ms"],
+                "launch_ms": roof["ms"],
+                "launches_timed": roof["launches"],
+                "timing": f"fixed leg, independent of --steps: {roof['launches']} launches of {roof['T']} steps (reset before each), all "
+                          "enqueued before the first event is waited on; HIP events on the launch stream around every launch",
             },
         }
+        if traffic_src:
+            line["roofline"]["traffic_source"] = traffic_src
         if args.reward == "pmi":
             H = args.pmi_hidden
             flop_pair = 2.0 * (12 * H + 3 * H * H + H)               # 101 632 at H = 128
-            tf = res["pmi_pairs"] * flop_pair / (res["kernel_ms_total"] * 1e-3) / 1e12
+            tf = roof["pmi_pairs"] * flop_pair / (sum(roof["ms"]) * 1e-3) / 1e12
             line["roofline_hbm_all_kernels"] = line["roofline"]
             line["roofline"] = {
                 "bound": "mfma", "kernel": "pmi_score_kernel", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s",
                 "frac": tf / 157.3, "traffic": None,
-                "flop_per_pair": flop_pair, "pairs_scored": res["pmi_pairs"],
-                "pairs_per_agent_step": res["pmi_pairs"] / (B * N * args.steps),
-                "timing": "HIP events around every uavtrack_step_many call of the timed region (all three kernels of "
-                          "each step: a lower bound for the scorer alone; the per-kernel split is in profiles/)",
+                "flop_per_pair": flop_pair, "pairs_scored": roof["pmi_pairs"],
+                "pairs_per_agent_step": roof["pmi_pairs"] / (units_per_launch * roof["launches"]),
+                "steps_per_launch": roof["T"], "launches_timed": roof["launches"], "avg_launch_ms": roof["avg_ms"],
+                "timing": "HIP events around every uavtrack_step_many call of the fixed leg (all kernels of each chunk: a "
+                          "lower bound for the scorer alone; the per-kernel split is in profiles/)",
                 "peak_note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak = fp32 vector peak, MI355X_MICROARCH.md",
             }
-        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(traffic_file):
-            try:
-                tr = json.load(open(traffic_file))
-                key = f"{B}x{N}x{M}_T{args.rollout}"
-                if key in tr and args.reward == "raw" and args.dim == 2:
-                    line["roofline"]["traffic"] = tr[key]["hbm_bytes_per_launch"]
-                    line["roofline"]["traffic_source"] = tr[key].get("source", "profiles/")
-            except Exception:
-                pass
         if args.policy == "actor":
             # the actor adds 2*(12*H + H*16*tiles) fp32 MFMA flops per agent-step (actions padded to 16-row tiles: 1 in 2-D, 3 in 3-D)
             Hp = (args.actor_hidden + 15) // 16 * 16
-            line["roofline"]["actor_mfma_flop_per_agent_step"] = 2 * (12 * Hp + Hp * 16 * (3 if args.dim == 3 else 1))
-            line["roofline"]["actor_mfma_tflops"] = line["roofline"]["actor_mfma_flop_per_agent_step"] * avg_units / (avg_launch_ms * 1e-3) / 1e12
-            line["roofline"]["note"] = ("closed-loop launch: environment step (HBM roofline above) plus the policy network on the "
-                                        "fp32 matrix cores (peak 157.3 TFLOP/s); both figures are over the whole launch")
+            rl = line["roofline"]
+            rl["actor_mfma_flop_per_agent_step"] = 2 * (12 * Hp + Hp * 16 * (3 if args.dim == 3 else 1))
+            rl["actor_mfma_tflops"] = rl["actor_mfma_flop_per_agent_step"] * units_per_launch / (roof["avg_ms"] * 1e-3) / 1e12
+            rl["note"] = ("closed-loop launch: environment step (HBM roofline above) plus the policy network on the "
+                          "fp32 matrix cores (peak 157.3 TFLOP/s); both figures are over the whole launch")
         if world == 1 and not args.no_extras and args.reward != "pmi" and args.policy == "given":
-            # the same kernel, one launch per env step (what a closed-loop policy would do eagerly)
-            # (host-bound, and the host side of a shared box is noisy -- 25 to 80 us per step have been seen
-            # for the same binary within one minute -- so: three short runs, the best one is reported)
-            k = min(args.steps, 400)
-            runs = [time_config(uavtrack, args, B, k, min(args.warmup, 100), 1, device) for _ in range(3)]
-            r1 = min(runs, key=lambda r: r["wall_s"])
-            line["per_step_launch"] = {
-                "agent_steps_per_s": B * N * k / r1["wall_s"], "ms_per_step": r1["wall_s"] * 1e3 / k,
-                "kernel_ms_per_step": r1["kernel_ms_total"] / r1["launches"],
-                "ms_per_step_all_runs": [r["wall_s"] * 1e3 / k for r in runs],
-                "note": "uavtrack_step eager from Python/ctypes, best of three 400-step runs; host-launch bound",
-            }
-            # a batch that fills the chip (SURVEY 8d 'bandwidth-saturating batch')
-            Bs, Ts, Ks = 65536, 50, 200
-            rs = time_config(uavtrack, args, Bs, Ks, Ts, Ts, device)
-            ach = bytes_unit * (Bs * N * Ks / rs["launches"]) / (rs["kernel_ms_total"] / rs["launches"] * 1e-3) / 1e9
-            line["saturating_batch"] = {
-                "workload": f"{Bs} envs x {N} UAVs x {M} targets, {Ts} steps per launch",
-                "agent_steps_per_s": Bs * N * Ks / rs["wall_s"],
-                "roofline_achieved_GBs": ach, "roofline_frac": ach / HBM_PEAK_GBS,
-                "avg_launch_ms": rs["kernel_ms_total"] / rs["launches"], "geometry": rs["geometry"],
-            }
-        if world == 1 and not args.no_extras and args.reward != "pmi" and args.policy == "given":
-            # closed loop: actor forward [B*N,12] -> sample -> uavtrack_step per step, eager
-            # launches vs the same steps replayed from a HIP graph
-            torch.manual_seed(args.seed)
-            actor = uavtrack.ActorMLP(hidden_dim=128, action_dim=12 * (3 if args.dim == 3 else 1)).to(device)
-            cl = {}
-            modes = ("eager", "graph", "actor_graph") + (("greedy_graph",) if args.dim == 2 else ())
-            for mode in modes:
-                env = make_env(uavtrack, args, B, device)
-                ro = uavtrack.BatchedRollout(env, "greedy" if mode == "greedy_graph" else actor, steps_per_graph=10,
-                                             use_graph=(mode != "eager"), device_actor=(mode == "actor_graph"))
-                ro.reset(seed=args.seed)
-                ro.run(40)
-                torch.cuda.synchronize(device)
-                t0 = time.perf_counter()
-                ro.run(400)
-                torch.cuda.synchronize(device)
-                dt = time.perf_counter() - t0
-                cl[mode] = {"agent_steps_per_s": B * N * 400 / dt, "ms_per_step": dt * 1e3 / 400}
-                env.close()
-            if args.dim == 2:      # the same closed loop fused into one launch per 200-step episode
-                env = make_env(uavtrack, args, B, device)
-                env.reset(seed=args.seed)
-                env.run_greedy(200, seed=args.seed)
-                torch.cuda.synchronize(device)
-                t0 = time.perf_counter()
-                for _ in range(5):
-                    env.reset(seed=args.seed)
-                    env.run_greedy(200, seed=args.seed)
-                torch.cuda.synchronize(device)
-                dt = time.perf_counter() - t0
-                cl["greedy_fused"] = {"agent_steps_per_s": B * N * 1000 / dt, "ms_per_step": dt * 1e3 / 1000}
-                env.close()
-            for _once in (0,):
-                # actor + environment of a whole 200-step episode in one launch (uavtrack_run_actor)
-                env = make_env(uavtrack, args, B, device)
-                env.set_actor(actor)
-                out = env.run_actor(200, env.reset(seed=args.seed), seed=args.seed, want_terms=False)
-                torch.cuda.synchronize(device)
-                t0 = time.perf_counter()
-                for _ in range(5):
-                    out = env.run_actor(200, env.reset(seed=args.seed), seed=args.seed, want_terms=False, out=out)
-                torch.cuda.synchronize(device)
-                dt = time.perf_counter() - t0
-                cl["actor_fused"] = {"agent_steps_per_s": B * N * 1000 / dt, "ms_per_step": dt * 1e3 / 1000}
-                env.close()
-            cl["note"] = ("reference-shaped shared actor (FnnPolicyNet 12-128-12 softmax as in configs/MAAC.yaml, random "
-                          "init) + categorical sample + uavtrack_step_accumulate, all on device; eager/graph = the actor "
-                          "forward and the sample as PyTorch ops, graph = 10 steps per HIP-graph replay; actor_graph = the same "
-                          "with the library's own actor kernel (uavtrack_actor_actions); actor_fused = uavtrack_run_actor, "
-                          "actor and step of a whole 200-step episode in one launch (the rollout of train.operate_epoch); "
-                          "greedy_graph / greedy_fused = the same two forms with the reference's C-METHOD baseline policy "
-                          "(uav.py:324-369) instead of the actor")
-            line["closed_loop"] = cl
+            line.update(extras(uavtrack, args, B, device, bytes_unit))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
             line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
@@ -463,6 +628,16 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, argv))        # the parent makes no GPU call, before or after
+    worker(args)
 
 
 if __name__ == "__main__":

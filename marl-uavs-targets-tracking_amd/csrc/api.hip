@@ -37,6 +37,32 @@ int fail(const char *fmt, ...)
         if (e__ != hipSuccess) return fail("%s: %s", #expr, hipGetErrorString(e__));   \
     } while (0)
 
+// Makes the handle's device current for the duration of one ABI call and gives the caller's device back on
+// return: a process that drives several shards, or keeps PyTorch on another GPU, must not find its current
+// device changed behind its back.
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            changed = (err == hipSuccess);
+        }
+    }
+    ~DeviceGuard()
+    {
+        if (changed) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define ON_DEVICE(dev)            \
+    DeviceGuard guard__(dev);     \
+    HIP_TRY(guard__.err)
+
 template <typename T>
 hipError_t dmalloc(T **p, size_t n)
 {
@@ -46,7 +72,7 @@ hipError_t dmalloc(T **p, size_t n)
 void free_state(uavtrack_env *env)
 {
     void *ptrs[] = {env->slab, env->pmi.blob, env->actor_w, env->pairs, env->pair_count, env->pair_total, env->scores, env->pose,
-                    env->obs_tmp, env->terms_tmp};
+                    env->obs_tmp, env->terms_tmp, env->covered_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -67,7 +93,11 @@ int validate(const uavtrack_config &c)
         return fail("reward_mode must be 0 (raw), 1 (mean) or 2 (pmi) (got %d)", c.reward_mode);
     if (c.horizon < 0) return fail("horizon must be >= 0");
     if (!(c.dc > 0) || !(c.dp > 0) || !(c.u_v_max > 0) || !(c.dt > 0)) return fail("dc, dp, u_v_max, dt must be > 0");
-    if ((int64_t)c.n_envs * c.n_uav * UAVTRACK_OBS_DIM > ((int64_t)1 << 40)) return fail("batch too large");
+    // the step kernel addresses a step's outputs as uniform base + 32-bit lane offset (largest row: obs, 48 B per agent)
+    if ((int64_t)c.n_envs * c.n_uav * UAVTRACK_OBS_DIM * 4 >= ((int64_t)1 << 32) ||
+        (int64_t)c.n_envs * c.m_targets >= ((int64_t)1 << 30))
+        return fail("batch too large: n_envs * n_uav must stay below %lld agents per GPU (got %lld)",
+                    (long long)(((int64_t)1 << 32) / (UAVTRACK_OBS_DIM * 4)), (long long)c.n_envs * c.n_uav);
     return 0;
 }
 
@@ -79,7 +109,8 @@ int ensure_pmi_scratch(uavtrack_env *env, int32_t steps, hipStream_t st)
     const uavtrack_config &c = env->cfg;
     const size_t BN = (size_t)c.n_envs * c.n_uav;
     const size_t pairs_step = BN * (c.n_uav - 1) / 2 + 1;
-    const size_t per_step = pairs_step * sizeof(uint2) + BN * c.n_uav * 4 + BN * 16 + BN * UAVTRACK_OBS_DIM * 4 + 3 * BN * 4;
+    const size_t per_step = pairs_step * sizeof(uint2) + BN * c.n_uav * 4 + BN * 16 + BN * UAVTRACK_OBS_DIM * 4 + 3 * BN * 4 +
+                            (size_t)c.n_envs * 4;
     size_t budget = (size_t)2048 << 20;
     if (const char *s = getenv("UAVTRACK_PMI_SCRATCH_MB")) budget = (size_t)atoll(s) << 20;
     int64_t cap = (int64_t)(budget / per_step);
@@ -89,10 +120,11 @@ int ensure_pmi_scratch(uavtrack_env *env, int32_t steps, hipStream_t st)
     if (cap > steps) cap = steps;
     if (cap <= env->pmi_steps_cap) return 0;
     HIP_TRY(hipStreamSynchronize(st));
-    void *old[] = {env->pairs, env->scores, env->pose, env->obs_tmp, env->terms_tmp};
+    void *old[] = {env->pairs, env->scores, env->pose, env->obs_tmp, env->terms_tmp, env->covered_tmp};
     for (void *q : old)
         if (q) (void)hipFree(q);
     env->pairs = nullptr; env->scores = nullptr; env->pose = nullptr; env->obs_tmp = nullptr; env->terms_tmp = nullptr;
+    env->covered_tmp = nullptr;
     env->pmi_steps_cap = 0;
     const size_t S = (size_t)cap;
     HIP_TRY(dmalloc(&env->pairs, S * pairs_step));
@@ -100,6 +132,7 @@ int ensure_pmi_scratch(uavtrack_env *env, int32_t steps, hipStream_t st)
     HIP_TRY(dmalloc(&env->pose, S * BN));
     HIP_TRY(dmalloc(&env->obs_tmp, S * BN * UAVTRACK_OBS_DIM));
     HIP_TRY(dmalloc(&env->terms_tmp, S * 3 * BN));
+    HIP_TRY(dmalloc(&env->covered_tmp, S * (size_t)c.n_envs));
     if (!env->pair_count) {
         HIP_TRY(dmalloc(&env->pair_count, 1));
         HIP_TRY(hipMemsetAsync(env->pair_count, 0, sizeof(unsigned), st));
@@ -178,7 +211,7 @@ int uavtrack_create(const uavtrack_config *cfg, uavtrack_env **out)
                     e != hipSuccess ? hipGetErrorString(e) : "device count 0");
     if (cfg->device_id < 0 || cfg->device_id >= ndev)
         return fail("uavtrack_create: device_id %d out of range [0, %d)", cfg->device_id, ndev);
-    HIP_TRY(hipSetDevice(cfg->device_id));
+    ON_DEVICE(cfg->device_id);
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, cfg->device_id));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -228,7 +261,7 @@ int uavtrack_create(const uavtrack_config *cfg, uavtrack_env **out)
 int uavtrack_destroy(uavtrack_env *env)
 {
     if (!env) return 0;
-    (void)hipSetDevice(env->cfg.device_id);
+    DeviceGuard guard(env->cfg.device_id);
     free_state(env);
     delete env;
     return 0;
@@ -237,7 +270,7 @@ int uavtrack_destroy(uavtrack_env *env)
 int uavtrack_reset(uavtrack_env *env, uint64_t seed, uint32_t episode, float *obs, void *stream)
 {
     if (!env) return fail("uavtrack_reset: null handle");
-    HIP_TRY(hipSetDevice(env->cfg.device_id));
+    ON_DEVICE(env->cfg.device_id);
     HIP_TRY(launch_reset(env, seed, episode, obs, static_cast<hipStream_t>(stream)));
     return 0;
 }
@@ -251,7 +284,7 @@ int uavtrack_set_state(uavtrack_env *env, const float *ux, const float *uy, cons
     const uavtrack_config &c = env->cfg;
     if (c.m_targets > 0 && (!tx || !ty || !th)) return fail("uavtrack_set_state: null target array");
     if (c.dim == 3 && (!uz || (c.m_targets > 0 && !tz))) return fail("uavtrack_set_state: dim == 3 needs uz and tz");
-    HIP_TRY(hipSetDevice(c.device_id));
+    ON_DEVICE(c.device_id);
     hipStream_t st = static_cast<hipStream_t>(stream);
     StateBlock &s = env->state;
     const size_t BN = (size_t)c.n_envs * c.n_uav * 4, BM = (size_t)c.n_envs * c.m_targets * 4;
@@ -280,7 +313,7 @@ int uavtrack_get_state(uavtrack_env *env, float *ux, float *uy, float *uz, float
 {
     if (!env) return fail("uavtrack_get_state: null handle");
     const uavtrack_config &c = env->cfg;
-    HIP_TRY(hipSetDevice(c.device_id));
+    ON_DEVICE(c.device_id);
     hipStream_t st = static_cast<hipStream_t>(stream);
     StateBlock &s = env->state;
     const size_t BN = (size_t)c.n_envs * c.n_uav * 4, BM = (size_t)c.n_envs * c.m_targets * 4;
@@ -305,7 +338,7 @@ int uavtrack_get_state(uavtrack_env *env, float *ux, float *uy, float *uz, float
 int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_floats, int32_t hidden, void *stream)
 {
     if (!env) return fail("uavtrack_set_pmi_weights: null handle");
-    HIP_TRY(hipSetDevice(env->cfg.device_id));
+    ON_DEVICE(env->cfg.device_id);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!folded) {
         HIP_TRY(hipStreamSynchronize(st));
@@ -355,7 +388,7 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
     if (T < 1) return fail("%s: T must be >= 1 (got %d)", who, T);
     if (pol.policy == kPolicyGiven && !actions) return fail("%s: actions is null", who);
     if (!reward) return fail("%s: reward is null", who);
-    HIP_TRY(hipSetDevice(env->cfg.device_id));
+    ON_DEVICE(env->cfg.device_id);
     hipStream_t st = static_cast<hipStream_t>(stream);
     StepParams p = env->base;
     p.actions = actions;
@@ -393,7 +426,8 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
         float *obs_t = obs ? obs + (size_t)t0 * BN * UAVTRACK_OBS_DIM : env->obs_tmp;
         float *terms_t = terms ? terms + (size_t)t0 * 3 * BN : (ep_sums ? env->terms_tmp : nullptr);
         float *reward_t = reward + (size_t)t0 * BN;
-        int32_t *covered_t = covered ? covered + (size_t)t0 * c.n_envs : nullptr;
+        // (the episode sums need the coverage counts even when the caller does not ask for them)
+        int32_t *covered_t = covered ? covered + (size_t)t0 * c.n_envs : (ep_sums ? env->covered_tmp : nullptr);
         p.T = n;
         p.actions = actions ? actions + (size_t)t0 * BN : nullptr;
         p.actions_out = pol.actions_out ? pol.actions_out + (size_t)t0 * BN : nullptr;
@@ -443,7 +477,7 @@ int uavtrack_run_greedy(uavtrack_env *env, int32_t T, uint64_t seed, int32_t *ac
     if (env->cfg.dim != 2) return fail("uavtrack_run_greedy: the reference baseline is planar (dim must be 2)");
     if (env->cfg.reward_mode == UAVTRACK_REWARD_PMI)
         return fail("uavtrack_run_greedy: the C-METHOD baseline runs with the MAAC / MAAC-G rewards (C-METHOD.yaml: cooperative 0)");
-    HIP_TRY(hipSetDevice(env->cfg.device_id));
+    ON_DEVICE(env->cfg.device_id);
     StepParams p = env->base;
     p.T = T;
     p.actions = nullptr; p.actions_out = actions_out;
@@ -461,7 +495,7 @@ int uavtrack_greedy_actions(uavtrack_env *env, uint64_t seed, int32_t *actions, 
     if (!env) return fail("uavtrack_greedy_actions: null handle");
     if (!actions) return fail("uavtrack_greedy_actions: actions is null");
     if (env->cfg.dim != 2) return fail("uavtrack_greedy_actions: the reference baseline is planar (dim must be 2)");
-    HIP_TRY(hipSetDevice(env->cfg.device_id));
+    ON_DEVICE(env->cfg.device_id);
     HIP_TRY(launch_greedy(env, seed, actions, static_cast<hipStream_t>(stream)));
     return 0;
 }
@@ -470,7 +504,7 @@ int uavtrack_set_actor_weights(uavtrack_env *env, const float *w1, const float *
                                int32_t hidden, void *stream)
 {
     if (!env) return fail("uavtrack_set_actor_weights: null handle");
-    HIP_TRY(hipSetDevice(env->cfg.device_id));
+    ON_DEVICE(env->cfg.device_id);
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIP_TRY(hipStreamSynchronize(st));
     if (!w1) {
@@ -507,7 +541,7 @@ int uavtrack_actor_actions(uavtrack_env *env, const float *obs, uint64_t seed, i
     if (!env->actor_w) return fail("uavtrack_actor_actions: needs uavtrack_set_actor_weights first");
     if (mode != UAVTRACK_ACTOR_SAMPLE && mode != UAVTRACK_ACTOR_ARGMAX)
         return fail("uavtrack_actor_actions: mode %d is neither UAVTRACK_ACTOR_SAMPLE nor UAVTRACK_ACTOR_ARGMAX", mode);
-    HIP_TRY(hipSetDevice(env->cfg.device_id));
+    ON_DEVICE(env->cfg.device_id);
     HIP_TRY(launch_actor(env, obs, seed, mode, actions, probs, static_cast<hipStream_t>(stream)));
     return 0;
 }
@@ -536,7 +570,7 @@ int uavtrack_pmi_pairs_scored(uavtrack_env *env, uint64_t *out, void *stream)
     if (!env || !out) return fail("uavtrack_pmi_pairs_scored: null argument");
     *out = 0;
     if (!env->pair_total) return 0;
-    HIP_TRY(hipSetDevice(env->cfg.device_id));
+    ON_DEVICE(env->cfg.device_id);
     hipStream_t st = static_cast<hipStream_t>(stream);
     unsigned long long v = 0;
     HIP_TRY(hipMemcpyAsync(&v, env->pair_total, sizeof v, hipMemcpyDeviceToHost, st));

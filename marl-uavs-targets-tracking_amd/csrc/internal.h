@@ -125,6 +125,7 @@ struct uavtrack_env {
     unsigned long long *pair_total = nullptr;
     float *scores = nullptr, *obs_tmp = nullptr, *terms_tmp = nullptr;
     float4 *pose = nullptr;
+    int32_t *covered_tmp = nullptr;   // [steps][B] coverage counts for ep_sums when the caller passes covered = NULL
 };
 
 namespace uavtrack {

@@ -144,6 +144,13 @@ __device__ __forceinline__ void sincos_any(float h, float *s, float *c)
     else sincosf(h, s, c);
 }
 
+// uniform base + zero-extended 32-bit per-lane byte offset: the form the global_load/store `saddr` encoding takes
+template <typename T>
+__device__ __forceinline__ T *at(T *base, unsigned byte_off)
+{
+    return (T *)((char *)base + byte_off);   // (char-pointer arithmetic keeps the global address space; an integer round trip would not)
+}
+
 // ---- LDS table geometry (float4 units) --------------------------------------------------
 __device__ __host__ __forceinline__ int pairs_of(int n) { return (n + 1) >> 1; }
 // coverage words per environment: 12 target PAIRS per word (two interleaved base-4 digit strings of 12 digits each,
@@ -406,6 +413,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     float er = 0, ett = 0, ebp = 0, edup = 0;    // episode accumulators (train.py:181-192)
     int ecov = 0;
     int pn = 0;                                   // which table copy is "post-move" this step
+    unsigned cov_pending = 0;                     // coverage word of the previous step (deferred read-back)
 
     // ---- load state once
     const StateBlock S = state_view(p.slab, p.B, N, M, Z3);
@@ -441,8 +449,15 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         thd[q] = th;
         if (Z3) tzf[te * MP * 2 + k] = S.tz[gt];
     }
+    // Per-step I/O addressing: every array is [t][...] with a uniform per-step stride, so the step loop
+    // advances uniform base pointers (SGPRs) and each lane adds one 32-bit offset (validate() bounds
+    // B * N * 48 below 4 GiB) -- `global_store ... v_off, s[base]` instead of 64-bit vector address math.
+    const unsigned g32 = (unsigned)g;
+    size_t row = 0;              // t * B * N: start of this step's [b][i] row in the per-step arrays (uniform)
+    size_t rowb = 0;             // t * B
+    int act_next = 0;
     int act = 0;
-    if (GIVEN && active) act = p.actions[g];
+    if (GIVEN && active) act = min(max(*at(p.actions, g32 * 4u), 0), p.na_total - 1);
     ActorRng arng;
     arng.valid = false; arng.block = 0;
     float o[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // this UAV's local state; the actor reads last step's
@@ -458,14 +473,16 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     const bool one_target_per_lane = E * M <= nthreads;
     const bool my_target = tid < envs_here * M;
     float *tgt = reinterpret_cast<float *>(ttab);
+    float ttx = 0, tty = 0, ttc = 1, tts = 0, tth = 0;   // the lane's own target, resident across the T steps
     if (my_target) {
         const int te = tid / M, k = tid - te * M;
         tgt = reinterpret_cast<float *>(ttab + te * tstride + (k >> 1) * 2) + (k & 1);
     }
     __syncthreads();
+    if (one_target_per_lane && my_target) { ttx = tgt[0]; tty = tgt[2]; ttc = tgt[4]; tts = tgt[6]; tth = thd[tid]; }
 
     for (int t = 0; t < p.T; ++t) {
-        const size_t tg_off = (size_t)t * BN + g;          // [t][b][i]
+        const unsigned tg_off = (unsigned)t * (unsigned)BN + g32;   // flat [t][b][i] (MAAC-R pair records; < 2^32 by ensure_pmi_scratch)
         const int cbuf = (t & 1) * E * CW;
 
         // ---- P0 (fused greedy rollout only): the C-METHOD baseline policy (uav.py:324-369) on the state as it
@@ -494,7 +511,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                                   [&](int j) { return upos_of(rows, j); },
                                   [&](int k) { return tpos_of(tenv, k); },
                                   [&](int k) { return ncnt[e * M + k]; });
-                if (p.actions_out) p.actions_out[tg_off] = act;
+                if (p.actions_out) *at(p.actions_out + row, g32 * 4u) = act;
             }
             __syncthreads();   // the policy has read the target table; now it may move
         }
@@ -505,7 +522,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             float *alds = reinterpret_cast<float *>(reinterpret_cast<char *>(smem4) + p.actor_lds_off) + (tid >> 6) * kActorLdsFloats;
             act = actor_pick<false, actor_tiles(Z3)>(o, alds, p.actor_w, p.actor_hblocks, p.na_total, (uint64_t)(p.env_offset + b),
                                     (uint32_t)count, i, p.greedy_k0, p.greedy_k1, p.actor_mode, nullptr, arng);
-            if (active && p.actions_out) p.actions_out[tg_off] = act;
+            if (active && p.actions_out) *at(p.actions_out + row, g32 * 4u) = act;
         }
 
         // ---- P1a: targets (target.py:27-60); straight flight, mirror at the walls
@@ -532,7 +549,26 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             }
         };
         if (one_target_per_lane) {
-            if (my_target) advance_target(tgt, tid);
+            // the owner lane holds (x, y, cos, sin, heading) in registers: no LDS read on the step's critical path
+            if (my_target) {
+                ttx = fmaf(p.dtv_t, ttc, ttx);
+                tty = fmaf(p.dtv_t, tts, tty);
+                tgt[0] = ttx; tgt[2] = tty;
+                bool turned = false;
+                float th = 0.0f;
+                if (0.0f > tty || tty > p.y_max) {
+                    th = -tth;
+                    turned = true;
+                } else if (ttx < 0.0f || ttx > p.x_max) {
+                    th = (tth > 0.0f) ? kPi - tth : -kPi - tth;
+                    turned = true;
+                }
+                if (turned) {   // rare: recompute so that T fused steps == T single steps bit for bit
+                    sincos_any(th, &tts, &ttc);
+                    tgt[4] = ttc; tgt[6] = tts;
+                    tth = th;
+                }
+            }
         } else {
             for (int q = tid; q < envs_here * M; q += nthreads) {
                 const int te = q / M, k = q - te * M;
@@ -545,7 +581,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         float ai = 0;
         const float xo = x, yo = y, zo = z, co = c, so = s, ao = (float)a_prev;   // pre-move pose: even-i self term
         if (active) {
-            a_now = min(max(act, 0), p.na_total - 1);
+            a_now = GIVEN ? act : min(max(act, 0), p.na_total - 1);   // (given actions are clamped where they are loaded)
             int a_turn = a_now, a_climb = 0;
             if (Z3) { a_climb = a_now / p.na; a_turn = a_now - a_climb * p.na; }
             float step_xy = p.dtv_u;
@@ -562,7 +598,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                 float *f = own0 + pn * 12;                   // copy pn of this lane's pair row
                 f[0] = x; f[2] = y; f[4] = c; f[6] = s; f[8] = ai; f[10] = z;
             }
-            if (GIVEN && t + 1 < p.T) act = p.actions[tg_off + BN];   // prefetch next step's action
+            if (GIVEN && t + 1 < p.T) act_next = *at(p.actions + row + BN, g32 * 4u);   // prefetch next step's action
             if (i == 0)
                 for (int w = 0; w < CW; ++w) covw[cbuf + e * CW + w] = 0;
         }
@@ -676,29 +712,43 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             r = fminf(fmaxf(r, -1.0f), 1.0f);   // clip_and_normalize(reward, -1, 1), environment.py:225
 
             ++count;
+            // the prefetched action is consumed HERE, ahead of this step's stores: vector-memory operations
+            // retire in order, so a first use at the top of the next step would wait for these stores too
+            if (GIVEN) act = min(max(act_next, 0), p.na_total - 1);
             if (i == 0) {
-                int cov = 0;
-                for (int w = 0; w < CW; ++w) cov += __popc(covw[cbuf + e * CW + w]);
-                ecov += cov;
-                const size_t tb = (size_t)t * p.B + b;
-                if (p.covered) p.covered[tb] = cov;
-                if (p.done) p.done[tb] = (p.horizon > 0 && count >= p.horizon) ? 1 : 0;
+                // Coverage count.  With one coverage word per environment (M <= 24) the LDS read-back is
+                // deferred by a step: this step's word is requested now and popcounted at the next step's
+                // P4 (or behind the loop), so its latency never sits on the critical path.
+                if (CW == 1) {
+                    if (t > 0) {
+                        const int cov = __popc(cov_pending);
+                        ecov += cov;
+                        if (p.covered) p.covered[rowb - p.B + b] = cov;          // row t - 1
+                    }
+                    cov_pending = covw[cbuf + e];
+                } else {
+                    int cov = 0;
+                    for (int w = 0; w < CW; ++w) cov += __popc(covw[cbuf + e * CW + w]);
+                    ecov += cov;
+                    if (p.covered) p.covered[rowb + b] = cov;
+                }
+                if (p.done) p.done[rowb + b] = (p.horizon > 0 && count >= p.horizon) ? 1 : 0;
             }
             er += r; ett += tt; ebp += bp; edup += dupn;
 
             if (p.obs) {
-                float4 *op = reinterpret_cast<float4 *>(p.obs + tg_off * UAVTRACK_OBS_DIM);
+                float4 *op = at(reinterpret_cast<float4 *>(p.obs + row * UAVTRACK_OBS_DIM), g32 * (unsigned)(UAVTRACK_OBS_DIM * 4));
                 op[0] = make_float4(o[0], o[1], o[2], o[3]);
                 op[1] = make_float4(o[4], o[5], o[6], o[7]);
                 op[2] = make_float4(o[8], o[9], o[10], o[11]);
             }
-            if (p.reward) p.reward[tg_off] = r;
-            if (p.pose_out) p.pose_out[tg_off] = make_float4(x, y, z, raw);
-            if (p.terms) {
-                float *tp = p.terms + (size_t)t * 3 * BN + g;   // [t][3][b][i]
-                tp[0] = tt;
-                tp[BN] = bp;
-                tp[2 * BN] = dupn;
+            if (p.reward) *at(p.reward + row, g32 * 4u) = r;
+            if (p.pose_out) *at(p.pose_out + row, g32 * 16u) = make_float4(x, y, z, raw);
+            if (p.terms) {                                    // [t][3][b][i]
+                float *tp = p.terms + 3 * row;
+                *at(tp, g32 * 4u) = tt;
+                *at(tp + BN, g32 * 4u) = bp;
+                *at(tp + 2 * BN, g32 * 4u) = dupn;
             }
             a_prev = a_now;
         }
@@ -748,6 +798,13 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             }
         }
         pn ^= 1;
+        row += BN;
+        rowb += (size_t)p.B;
+    }
+    if (CW == 1 && active && i == 0) {       // the last step's deferred coverage count
+        const int cov = __popc(cov_pending);
+        ecov += cov;
+        if (p.covered) p.covered[rowb - p.B + b] = cov;
     }
 
     // ---- store state once
@@ -756,11 +813,18 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         if (Z3) S.uz[g] = z;
         if (i == 0) S.step_count[b] = count;
     }
-    for (int q = tid; q < envs_here * M; q += nthreads) {
-        const int te = q / M, k = q - te * M;
-        const size_t gt = (size_t)env0 * M + q;
-        const float *f = reinterpret_cast<const float *>(ttab + te * tstride + (k >> 1) * 2);
-        S.tx[gt] = f[k & 1]; S.ty[gt] = f[2 + (k & 1)]; S.th[gt] = thd[q];
+    if (one_target_per_lane) {
+        if (my_target) {
+            const size_t gt = (size_t)env0 * M + tid;
+            S.tx[gt] = ttx; S.ty[gt] = tty; S.th[gt] = tth;
+        }
+    } else {
+        for (int q = tid; q < envs_here * M; q += nthreads) {
+            const int te = q / M, k = q - te * M;
+            const size_t gt = (size_t)env0 * M + q;
+            const float *f = reinterpret_cast<const float *>(ttab + te * tstride + (k >> 1) * 2);
+            S.tx[gt] = f[k & 1]; S.ty[gt] = f[2 + (k & 1)]; S.th[gt] = thd[q];
+        }
     }
     if (p.ep_sums) {
         __syncthreads();                       // everyone is done with the tables

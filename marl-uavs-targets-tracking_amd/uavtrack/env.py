@@ -58,6 +58,26 @@ class BatchedUavEnv:
     def _empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.device)
 
+    def _fits(self, t, shape, dtype) -> bool:
+        """True if `t` can be handed to a kernel that writes a contiguous `shape` / `dtype` array on this device."""
+        return (t is not None and tuple(t.shape) == tuple(shape) and t.dtype == dtype and t.device == self.device
+                and t.is_contiguous())
+
+    def _reuse(self, o, key, shape, dtype, want=True):
+        """Output buffer `key` of a previous result `o` if it has exactly the shape this launch writes, else a
+        fresh one (a kernel writing T2 rows into a T1-row buffer would corrupt device memory)."""
+        if not want:
+            return None
+        t = o.get(key) if o else None
+        return t if self._fits(t, shape, dtype) else self._empty(shape, dtype)
+
+    def _out_arg(self, t, shape, dtype, name):
+        if t is None:
+            return self._empty(shape, dtype)
+        if not self._fits(t, shape, dtype):
+            raise ValueError(f"{name} must be a contiguous {dtype} {tuple(shape)} tensor on {self.device}")
+        return t
+
     def _actions(self, actions, shape) -> torch.Tensor:
         a = torch.as_tensor(actions)
         if a.device != self.device or a.dtype != torch.int32:
@@ -133,12 +153,7 @@ class BatchedUavEnv:
         o = out or {}
 
         def buf(key, shape, dtype, want=True):
-            if not want:
-                return None
-            t = o.get(key)
-            if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
-                t = self._empty(shape, dtype)
-            return t
+            return self._reuse(o, key, shape, dtype, want)
 
         obs = buf("obs", (T, self.B, self.N, _lib.OBS_DIM), torch.float32, want_obs)
         reward = buf("reward", (T, self.B, self.N), torch.float32)
@@ -194,7 +209,7 @@ class BatchedUavEnv:
 
     def greedy_actions(self, seed: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The reference's C-METHOD baseline policy (uav.py:324-369) for every UAV -> int32 [B, N]."""
-        a = out if out is not None else self._empty((self.B, self.N), torch.int32)
+        a = self._out_arg(out, (self.B, self.N), torch.int32, "out")
         _lib.check(self._lib.uavtrack_greedy_actions(self._h, C.c_uint64(seed & (2 ** 64 - 1)), _ptr(a),
                                                      self._stream()), "uavtrack_greedy_actions")
         return a
@@ -241,7 +256,7 @@ class BatchedUavEnv:
         if obs.shape != (self.B, self.N, _lib.OBS_DIM) or obs.dtype != torch.float32 or not obs.is_contiguous() \
                 or obs.device != self.device:
             raise ValueError(f"obs must be a contiguous float32 [{self.B}, {self.N}, {_lib.OBS_DIM}] tensor on {self.device}")
-        a = out if out is not None else self._empty((self.B, self.N), torch.int32)
+        a = self._out_arg(out, (self.B, self.N), torch.int32, "out")
         probs = self._empty((self.B, self.N, self.cfg.na_total), torch.float32) if want_probs else None
         _lib.check(self._lib.uavtrack_actor_actions(self._h, _ptr(obs), C.c_uint64(seed & (2 ** 64 - 1)),
                                                     C.c_int32(mode), _ptr(a), _ptr(probs), self._stream()),
@@ -258,10 +273,7 @@ class BatchedUavEnv:
         o = out or {}
 
         def buf(key, shape, dtype, want=True):
-            if not want:
-                return None
-            t = o.get(key)
-            return t if t is not None else self._empty(shape, dtype)
+            return self._reuse(o, key, shape, dtype, want)
         acts = buf("actions", (T, self.B, self.N), torch.int32)
         obs = buf("obs", (T, self.B, self.N, _lib.OBS_DIM), torch.float32)
         reward = buf("reward", (T, self.B, self.N), torch.float32)

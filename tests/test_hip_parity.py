@@ -664,30 +664,41 @@ def test_plain_c_client_matches_python_host_layer(uavtrack, tmp_path):
 
 
 def test_bench_contract_line(uavtrack):
-    """bench.py prints ONE JSON line with the driver's keys, the roofline and cpu_baseline objects, and a value
-    that agrees with its own ms_per_step (short run: 400 timed steps, 2 s of CPU baseline)."""
+    """bench.py as the driver runs it (--steps 20 --warmup 5) prints ONE JSON line with the driver's keys, the
+    roofline and cpu_baseline objects; `value` agrees with its own ms_per_step; `config.launch` names the launches
+    that were really timed; the roofline comes from the fixed 200-step leg, whatever --steps was."""
     import json
     import os
     import subprocess
     import sys
     from conftest import ROOT
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "400", "--warmup", "200",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5",
                         "--cpu-seconds", "2", "--no-extras"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "rccl_world_size"):
         assert k in d, k
     assert d["metric"] == "env agent-steps/sec" and d["unit"] == "agent-steps/s" and d["n_gpus"] == 1
-    assert d["steps"] == 400 and d["warmup"] == 200 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - 4096 * 20 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert d["value"] > 1e9                                   # > 100x the 10 M north-star floor
+    cfg = d["config"]
+    assert cfg["timed_launch_steps"] == [20] and cfg["warmup_launch_steps"] == [5]
+    assert "1 x 20 steps" in cfg["launch"] and "200 steps per call" not in cfg["launch"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.05 < rf["frac"] < 1.0
+    assert rf["steps_per_launch"] == 200 and rf["launches_timed"] >= 5 and len(rf["launch_ms"]) == rf["launches_timed"]
+    assert rf["agent_steps_per_launch"] == 4096 * 20 * 200
+    want = rf["algorithmic_bytes_per_agent_step"] * rf["agent_steps_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e9
+    assert abs(rf["achieved"] - want) / want < 1e-9 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert 0.30 < rf["frac"] < 1.0                            # round 1 measured 0.345 on this leg's launch shape
+    assert max(rf["launch_ms"]) < 1.25 * min(rf["launch_ms"])  # back-to-back launches: no host latency inside an event pair
+    if rf["traffic"] is not None:                             # only ever the profile of exactly this launch shape
+        assert "T200" in rf["traffic_source"] or "4096x20x10" in rf["traffic_source"] or rf["traffic"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 1e5 and "sample" in cb
 

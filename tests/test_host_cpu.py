@@ -257,12 +257,18 @@ def test_c_abi_builds_from_plain_c_and_fails_loudly_without_gpu(tmp_path):
     assert "no HIP device" in r.stderr and "no CPU fallback" in r.stderr
 
 
-def test_bench_launch_plan_and_cores():
-    """bench.launch_plan: at most `rollout` steps per launch, never across an episode end, sums to `steps`."""
+def _load_bench():
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
+    return bench
+
+
+def test_bench_launch_plan_and_cores():
+    """bench.launch_plan: at most `rollout` steps per launch, never across an episode end, sums to `steps`;
+    describe_plan names exactly those launches (the driver's --steps 20 --warmup 5 is ONE 20-step launch)."""
+    bench = _load_bench()
     for steps, rollout, horizon, pos in ((2000, 200, 200, 0), (1000, 1, 200, 0), (950, 64, 200, 130), (7, 200, 200, 199)):
         plan, end = bench.launch_plan(steps, rollout, horizon, pos)
         assert sum(plan) == steps and max(plan) <= rollout and min(plan) >= 1
@@ -271,7 +277,37 @@ def test_bench_launch_plan_and_cores():
             assert p + T <= horizon          # a launch never spans two episodes
             p = (p + T) % horizon
         assert end == p
+    warm, pos = bench.launch_plan(5, 200, 200, 0)
+    timed, _ = bench.launch_plan(20, 200, 200, pos)
+    assert warm == [5] and timed == [20] and bench.describe_plan(timed) == "1 x 20 steps"
+    assert bench.describe_plan([195, 200, 200, 5]) == "1 x 195 + 2 x 200 + 1 x 5 steps"
     assert 1 <= bench.host_cores() <= os.cpu_count()
+
+
+def test_bench_gpus_n_starts_n_ranks_or_fails():
+    """`python bench.py --gpus N` (no torchrun) starts N ranks itself: the launcher self-test (no GPU: gloo
+    rendezvous + all-reduce) reports n_gpus == rccl_world_size == 2 on ONE line; without enough GPUs, or with a
+    WORLD_SIZE that disagrees with --gpus, the run exits non-zero instead of reporting fewer GPUs."""
+    import json
+    import subprocess
+    import sys
+    exe = [sys.executable, os.path.join(ROOT, "bench.py")]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run(exe + ["--gpus", "2", "--backend", "gloo", "--selftest-launcher"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_world_size"] == 2 and d["gpus_requested"] == 2
+    # a rank count that cannot be honoured is an error, never a silent 1-GPU run
+    r = subprocess.run(exe + ["--gpus", "2", "--selftest-launcher"], capture_output=True, text=True, timeout=120,
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
+    if not _have_gpu():
+        r = subprocess.run(exe + ["--gpus", "2", "--steps", "5", "--warmup", "1"], capture_output=True, text=True,
+                           timeout=120, env=env)
+        assert r.returncode != 0 and "refusing" in r.stderr and not r.stdout.strip()
 
 
 def test_pmi_net_is_state_dict_compatible_and_folds(pmi_state_dict):
