@@ -227,33 +227,48 @@ def alloc_outputs(args, B, T, device):
     return out
 
 
-def run_rollouts(env, actions, plan, ep_steps, out, events=None, gather=None, policy="given", obs=None):
+def run_rollouts(env, actions, plan, ep_steps, out, gather=None, policy="given", obs=None, bound=None):
     """Issue the launches of `plan`; gathers the episode summaries and resets at every episode end.
-    obs: the observation the in-kernel policy sees first (policy != "given")."""
-    import torch
+    obs: the observation the in-kernel policy sees first (policy != "given").
+    bound: pre-built launch callables from bind_plan (the timed region replays those: no per-call Python beyond the
+    ctypes call itself)."""
     horizon = env.cfg.horizon
-    for T in plan:
-        if events is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        if policy == "actor":
+    for k, T in enumerate(plan):
+        if bound is not None:
+            res = bound["launch"][k]()
+        elif policy == "actor":
             res = env.run_actor(T, obs, seed=42, out=out.get(T))
             obs = res["obs"][-1]
         elif policy == "greedy":
             res = env.run_greedy(T, seed=42)
         else:
             res = env.step_many(actions[ep_steps:ep_steps + T], out=out.get(T))   # the episode's own action rows
-        if events is not None:
-            e1.record()
-            events.append((e0, e1, T))
         out[T] = res
         ep_steps += T
         if ep_steps >= horizon:               # end of an episode: gather summaries, start the next one
             if gather is not None:
                 gather(res["ep_sums"])
-            obs = env.reset(seed=42)
+            if bound is not None:
+                bound["episode"] += 1
+                obs = bound["reset"](bound["episode"])
+            else:
+                obs = env.reset(seed=42)
             ep_steps = 0
     return len(plan), obs
+
+
+def bind_plan(env, actions, plan, ep_steps, out, device):
+    """Pre-built launch callables for `plan` (pre-sampled actions only): the timed region then issues exactly the
+    library calls, nothing else."""
+    import torch
+    import uavtrack._lib as _l
+    horizon = env.cfg.horizon
+    launches = []
+    for T in plan:
+        launches.append(env.bind_step_many(actions[ep_steps:ep_steps + T], out[T]))
+        ep_steps = (ep_steps + T) % horizon
+    obs = torch.empty(env.B, env.N, _l.OBS_DIM, device=device)
+    return dict(launch=launches, reset=env.bind_reset(42, obs), episode=1 << 20)
 
 
 def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, env_offset=0, total_envs=None):
@@ -277,6 +292,7 @@ def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, en
     out = {T: alloc_outputs(args, B, T, device) for T in set(timed_plan) | set(warm_plan)}
     obs0 = env.reset(seed=args.seed)
     _, obs0 = run_rollouts(env, actions, warm_plan, 0, out, gather=gather, policy=args.policy, obs=obs0)
+    bound = bind_plan(env, actions, timed_plan, pos, out, device) if args.policy == "given" else None
     if gather is not None:
         for h in pending:
             h.wait()
@@ -284,9 +300,8 @@ def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, en
     torch.cuda.synchronize(device)
     if gather is not None:
         dist.barrier()
-    events = []
     t0 = time.perf_counter()
-    launches, _ = run_rollouts(env, actions, timed_plan, pos, out, events=events, gather=gather, policy=args.policy, obs=obs0)
+    launches, _ = run_rollouts(env, actions, timed_plan, pos, out, gather=gather, policy=args.policy, obs=obs0, bound=bound)
     if gather is not None:
         summaries = [h.wait() for h in pending]
         assert all(s.shape[0] == total_envs for s in summaries)
@@ -294,10 +309,9 @@ def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, en
     if gather is not None:
         dist.barrier()
     wall = time.perf_counter() - t0
-    kern_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in events)
     info = env.kernel_info()
     env.close()
-    return dict(wall_s=wall, kernel_ms_total=kern_ms, launches=launches, steps=steps, geometry=info,
+    return dict(wall_s=wall, launches=launches, steps=steps, geometry=info,
                 timed_plan=timed_plan, warm_plan=warm_plan)
 
 
@@ -416,7 +430,6 @@ def extras(uavtrack, args, B, device, bytes_unit):
     r1 = min(runs, key=lambda r: r["wall_s"])
     out["per_step_launch"] = {
         "agent_steps_per_s": B * N * k / r1["wall_s"], "ms_per_step": r1["wall_s"] * 1e3 / k,
-        "kernel_ms_per_step": r1["kernel_ms_total"] / r1["launches"],
         "ms_per_step_all_runs": [r["wall_s"] * 1e3 / k for r in runs],
         "note": "uavtrack_step eager from Python/ctypes, best of three 400-step runs; host-launch bound",
     }

@@ -560,6 +560,10 @@ int uavtrack_run_actor(uavtrack_env *env, int32_t T, uint64_t seed, int32_t mode
     if (obs_in == obs && T > 1)
         return fail("uavtrack_run_actor: obs_in must not alias obs when T > 1 (pass the previous launch's last rows, "
                     "or a copy)");
+    if (rollout_lds_bytes(env, kPolicyActor) > 64 * 1024)
+        return fail("uavtrack_run_actor: the step tables (%zu B) plus the actor's %zu B of LDS per workgroup exceed 64 KiB for "
+                    "n_uav=%d, m_targets=%d; use uavtrack_actor_actions + uavtrack_step for this shape",
+                    env->geo.lds_bytes, rollout_lds_bytes(env, kPolicyActor) - env->geo.lds_bytes, env->cfg.n_uav, env->cfg.m_targets);
     PolicyArgs pol;
     pol.policy = kPolicyActor; pol.obs_in = obs_in; pol.actions_out = actions_out; pol.seed = seed; pol.mode = mode;
     return run_steps(env, T, nullptr, obs, reward, terms, covered, done, ep_sums, stream, "uavtrack_run_actor", false, pol);

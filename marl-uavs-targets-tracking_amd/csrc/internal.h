@@ -134,6 +134,7 @@ namespace uavtrack {
 Geometry plan_geometry(const uavtrack_config &cfg, int n_simd);
 enum { kPolicyGiven = 0, kPolicyGreedy = 1, kPolicyActor = 2 };   // where a rollout's actions come from
 hipError_t launch_rollout(const uavtrack_env *env, const StepParams &p, hipStream_t stream, int policy = kPolicyGiven);
+size_t rollout_lds_bytes(const uavtrack_env *env, int policy);   // dynamic LDS of a rollout launch with that policy
 
 // pmi_kernel.hip
 bool pmi_hidden_supported(int hidden);

@@ -363,11 +363,13 @@ hipError_t launch_pmi_finalize(const uavtrack_env *env, int steps, float *reward
     FinalizeParams f;
     f.pose = env->pose; f.scores = env->scores; f.reward = reward;
     f.pair_count = env->pair_count;
-    f.SB = steps * c.n_envs; f.N = c.n_uav; f.E = env->geo.envs_per_wg; f.three_d = c.dim == 3;
+    // one lane per UAV-step (the rollout kernel's lanes hold UAV pairs: this kernel has its own geometry)
+    const int wgs = c.n_uav <= 256 ? 256 : kMaxWorkgroup;
+    f.SB = steps * c.n_envs; f.N = c.n_uav; f.E = wgs / c.n_uav; f.three_d = c.dim == 3;
     f.dp2 = env->base.dp2; f.coop = env->base.coop;
     const unsigned groups = (unsigned)((f.SB + f.E - 1) / f.E);
     const size_t lds = (size_t)f.E * f.N * 16;
-    hipLaunchKernelGGL(pmi_finalize_kernel, dim3(groups), dim3(env->geo.wgs), lds, stream, f);
+    hipLaunchKernelGGL(pmi_finalize_kernel, dim3(groups), dim3(wgs), lds, stream, f);
     return hipGetLastError();
 }
 
@@ -375,9 +377,10 @@ hipError_t launch_ep_sums(const uavtrack_env *env, int steps, const float *rewar
                           const int32_t *covered, float *ep_sums, bool add, hipStream_t stream)
 {
     const uavtrack_config &c = env->cfg;
-    EpParams q{reward, terms, covered, ep_sums, steps, c.n_envs, c.n_uav, env->geo.envs_per_wg, add ? 1 : 0};
+    const int wgs = c.n_uav <= 256 ? 256 : kMaxWorkgroup;
+    EpParams q{reward, terms, covered, ep_sums, steps, c.n_envs, c.n_uav, wgs / c.n_uav, add ? 1 : 0};
     const size_t lds = (size_t)q.E * q.N * 16;
-    hipLaunchKernelGGL(ep_sums_kernel, dim3(env->geo.groups), dim3(env->geo.wgs), lds, stream, q);
+    hipLaunchKernelGGL(ep_sums_kernel, dim3((unsigned)((c.n_envs + q.E - 1) / q.E)), dim3(wgs), lds, stream, q);
     return hipGetLastError();
 }
 

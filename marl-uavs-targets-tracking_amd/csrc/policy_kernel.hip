@@ -132,12 +132,19 @@ hipError_t launch_greedy(const uavtrack_env *env, uint64_t seed, int32_t *action
     p.tx = env->state.tx; p.ty = env->state.ty;
     p.step_count = env->state.step_count;
     p.actions = actions;
-    p.B = c.n_envs; p.N = c.n_uav; p.M = c.m_targets; p.E = env->geo.envs_per_wg; p.na = c.na;
+    p.B = c.n_envs; p.N = c.n_uav; p.M = c.m_targets; p.na = c.na;
     p.dc2 = env->base.dc2; p.turn_unit = env->base.turn_unit;
     p.env_offset = c.env_offset;
     p.k0 = (uint32_t)seed; p.k1 = (uint32_t)(seed >> 32);
-    const size_t lds = (size_t)p.E * (p.N * 8 + p.M * 8 + p.M * 4);
-    hipLaunchKernelGGL(greedy_policy_kernel, dim3(env->geo.groups), dim3(env->geo.wgs), lds, stream, p);
+    // this kernel's own geometry: one lane per UAV, whole environments per workgroup (the rollout kernel's
+    // lanes hold UAV pairs)
+    const int wgs = p.N <= 256 ? 256 : kMaxWorkgroup;
+    auto lds_of = [&](int E) { return (size_t)E * (p.N * 8 + p.M * 8 + p.M * 4); };
+    int E = wgs / p.N;
+    while (E > 1 && lds_of(E) > 64 * 1024) --E;
+    p.E = E;
+    const unsigned groups = (unsigned)((p.B + E - 1) / E);
+    hipLaunchKernelGGL(greedy_policy_kernel, dim3(groups), dim3(wgs), lds_of(E), stream, p);
     return hipGetLastError();
 }
 

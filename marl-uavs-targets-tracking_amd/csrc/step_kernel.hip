@@ -44,6 +44,13 @@
 #ifndef UAVTRACK_UNROLL_U
 #define UAVTRACK_UNROLL_U 5
 #endif
+// peer-table copy select of the sweep: 1 = bit test + multiply-add on a per-lane mask, 0 = compare + select
+#ifndef UAVTRACK_SEL_BITS
+#define UAVTRACK_SEL_BITS 0
+#endif
+#ifndef UAVTRACK_BRANCHFREE
+#define UAVTRACK_BRANCHFREE 1
+#endif
 #ifndef UAVTRACK_UNROLL_T
 #define UAVTRACK_UNROLL_T 5
 #endif
@@ -243,11 +250,21 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
     //      sequential view (<= dc)
     sx = splat(0.f); sy = splat(0.f); sc = splat(0.f); ss = splat(0.f); cnt = splat(0.f);
     v2f sa = splat(0.f), dup = splat(0.f);
+#if UAVTRACK_SEL_BITS
+    unsigned selbits = (1u << ((i + 1) >> 1)) - 1u;            // bit jp set iff 2 jp < i   (i <= 63 here: NP <= 32 rows)
+    asm("" : "+v"(selbits));   // opaque: the optimiser would turn the bit tests back into compare masks held in (spilled) SGPRs
+    const int dsel = (int)(rowNew - rowOld);                   // +-3 float4
+#endif
     constexpr bool NBF = NB && N_ > 0 && (N_ + 1) / 2 <= kCovPairs;
     v2f nbf = splat(0.f);
 #pragma unroll UU
     for (int jp = 0; jp < NP; ++jp) {
+#if UAVTRACK_SEL_BITS
+        // post-move copy iff 2 jp < i: bit jp of a per-lane mask, as an address offset (no compare masks to keep in SGPRs)
+        const float4 *rs = rowOld + (int)((selbits >> jp) & 1u) * dsel;   // one select serves pose, heading, action, z
+#else
         const float4 *rs = (2 * jp < i) ? rowNew : rowOld;   // one select serves pose, heading, action, z
+#endif
         const float4 n0 = rowNew[jp * 6];
         const float4 m0 = rs[jp * 6], m1 = rs[jp * 6 + 1], m2 = rs[jp * 6 + 2];
         const v2f dxn = (v2f){n0.x, n0.y} - xi2, dyn = (v2f){n0.z, n0.w} - yi2;
@@ -369,13 +386,18 @@ __device__ __forceinline__ void sweep_weighted(const StepParams &p, int N, int M
     }
 }
 
-template <int N_, int M_, int MODE, bool Z3, int POLICY>
+// ALLOUT: the caller passed every per-step output (obs, reward, terms, covered, done) -- the rollout a learner
+// consumes and the benchmark workload; the nullable-pointer tests and their SGPR flags then fold away.
+template <int N_, int M_, int MODE, bool Z3, int POLICY, bool ALLOUT = false>
 __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams p)
 {
     constexpr bool GREEDY = POLICY == kPolicyGreedy;
     constexpr bool ACTOR = POLICY == kPolicyActor;
     constexpr bool GIVEN = POLICY == kPolicyGiven;
     extern __shared__ float4 smem4[];
+    if (ALLOUT) __builtin_assume(p.obs != nullptr && p.reward != nullptr && p.terms != nullptr && p.covered != nullptr && p.done != nullptr);
+    if (MODE != UAVTRACK_REWARD_PMI) __builtin_assume(p.pose_out == nullptr);      // the MAAC-R chunk driver alone passes it
+    if (POLICY == kPolicyGiven) __builtin_assume(p.actions != nullptr);
     const int N = N_ > 0 ? N_ : p.N;
     const int M = M_ > 0 ? M_ : p.M;
     const int E = p.E;
@@ -620,7 +642,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             // wave-uniform branch the (differently rounded) literal path would also be taken by whichever other
             // environments happen to share the wavefront, and a shard of a batch would no longer reproduce the
             // unsharded batch bit for bit.  Wavefronts that hold such a UAV (rare) run both paths.
-            const bool near0 = fabsf(x) < 2.5f && fabsf(y) < 2.5f;
+            const bool near0 = fmaxf(fabsf(x), fabsf(y)) < 2.5f;
             if (__builtin_expect(near0, 0)) {
                 sweep_weighted<Z3>(p, N, M, i, rowNew, rowOld, tenv, tzrow, covw, cbuf + e * CW,
                                    x, y, z, c, s, ai, acc);
@@ -637,6 +659,21 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             }
 
             // ---- P3: local state (uav.py:156-190)
+#if UAVTRACK_BRANCHFREE
+            {   // empty list -> -1 (uav.py:174,186): computed unconditionally, selected afterwards (0 * rcp(0) never survives)
+                const float rcU = fast_rcp(acc.cntU), rcT = fast_rcp(acc.cntT);
+                const bool anyU = acc.cntU > 0.0f, anyT = acc.cntT > 0.0f;
+                o[0] = anyU ? acc.sxU * p.inv_dc * rcU : -1.0f;
+                o[1] = anyU ? acc.syU * p.inv_dc * rcU : -1.0f;
+                o[2] = anyU ? acc.scU * rcU : -1.0f;
+                o[3] = anyU ? acc.ssU * rcU : -1.0f;
+                o[4] = anyU ? acc.saU * p.inv_na_total * rcU : -1.0f;
+                o[5] = anyT ? acc.sxT * p.inv_dp * rcT : -1.0f;
+                o[6] = anyT ? acc.syT * p.inv_dp * rcT : -1.0f;
+                o[7] = anyT ? acc.scT * rcT : -1.0f;
+                o[8] = anyT ? acc.ssT * rcT : -1.0f;
+            }
+#else
             if (acc.cntU > 0.0f) {
                 const float rc = fast_rcp(acc.cntU);
                 o[0] = acc.sxU * p.inv_dc * rc;
@@ -656,6 +693,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             } else {
                 o[5] = o[6] = o[7] = o[8] = -1.0f;
             }
+#endif
             o[9] = x * p.inv_dc;
             o[10] = y * p.inv_dc;
             o[11] = ai * p.inv_na_total;
@@ -663,10 +701,18 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             // ---- raw reward terms, clipped and normalised (environment.py:207-220)
             float d_bdr = fminf(fminf(x, p.x_max - x), fminf(y, p.y_max - y));
             if (Z3) d_bdr = fminf(d_bdr, fminf(z, p.z_max - z));
+#if UAVTRACK_BRANCHFREE
+            // boundary punishment (uav.py:231-260) and its normalisation (environment.py:209,216), folded:
+            //   d < 0: -0.5 -> -1;  0 <= d < dp: -0.5 (dp - d) / dp -> d / dp - 1;  d >= dp: 0 -> 0   ==  clamp(d / dp, 0, 1) - 1
+            bp = __builtin_amdgcn_fmed3f(d_bdr * p.inv_dp, 0.0f, 1.0f) - 1.0f;
+            tt = __builtin_amdgcn_fmed3f(acc.trk, 0.0f, p.tt_ceil) * p.inv_tt_ceil;
+            dupn = (__builtin_amdgcn_fmed3f(acc.dup * -0.5f, p.dup_floor, 0.0f) - p.dup_floor) * p.inv_dup - 1.0f;
+#else
             float bpun = (d_bdr >= 0.0f) ? ((d_bdr < p.dp) ? -0.5f * (p.dp - d_bdr) * p.inv_dp : 0.0f) : -0.5f;
             tt = fminf(fmaxf(acc.trk, 0.0f), p.tt_ceil) * p.inv_tt_ceil;
             bp = (fminf(fmaxf(bpun, -0.5f), 0.0f) + 0.5f) * 2.0f - 1.0f;
             dupn = (fminf(fmaxf(acc.dup * -0.5f, p.dup_floor), 0.0f) - p.dup_floor) * p.inv_dup - 1.0f;
+#endif
             raw = p.alpha * tt + p.beta * bp + p.gamma * dupn;
             if (MODE != UAVTRACK_REWARD_RAW) rawl[e * (N + 1) + i] = raw;
         }
@@ -861,8 +907,22 @@ size_t lds_bytes_for(int E, int N, int M, bool z3)
 using KernelFn = void (*)(const StepParams);
 
 template <int N_, int M_>
-KernelFn pick_mode(int mode, bool z3, int policy)
+KernelFn pick_mode(int mode, bool z3, int policy, bool allout)
 {
+    if (policy == kPolicyGiven && allout) {
+        if (z3) {
+            switch (mode) {
+            case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, true, kPolicyGiven, true>;
+            case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, UAVTRACK_REWARD_PMI, true, kPolicyGiven, true>;
+            default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, true, kPolicyGiven, true>;
+            }
+        }
+        switch (mode) {
+        case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, false, kPolicyGiven, true>;
+        case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, UAVTRACK_REWARD_PMI, false, kPolicyGiven, true>;
+        default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, false, kPolicyGiven, true>;
+        }
+    }
     if (policy == kPolicyGreedy) {   // planar baseline policy; MAAC / MAAC-G rewards
         return mode == UAVTRACK_REWARD_MEAN ? rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, false, kPolicyGreedy>
                                             : rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, false, kPolicyGreedy>;
@@ -895,15 +955,15 @@ KernelFn pick_mode(int mode, bool z3, int policy)
     }
 }
 
-KernelFn pick_kernel(int N, int M, int mode, bool z3, int *specialised, int policy = kPolicyGiven)
+KernelFn pick_kernel(int N, int M, int mode, bool z3, int *specialised, int policy = kPolicyGiven, bool allout = false)
 {
     *specialised = 1;
-    if (N == 20 && M == 10) return pick_mode<20, 10>(mode, z3, policy);
-    if (N == 50 && M == 25) return pick_mode<50, 25>(mode, z3, policy);
-    if (N == 10 && M == 10) return pick_mode<10, 10>(mode, z3, policy);
-    if (N == 5 && M == 3) return pick_mode<5, 3>(mode, z3, policy);
+    if (N == 20 && M == 10) return pick_mode<20, 10>(mode, z3, policy, allout);
+    if (N == 50 && M == 25) return pick_mode<50, 25>(mode, z3, policy, allout);
+    if (N == 10 && M == 10) return pick_mode<10, 10>(mode, z3, policy, allout);
+    if (N == 5 && M == 3) return pick_mode<5, 3>(mode, z3, policy, allout);
     *specialised = 0;
-    return pick_mode<0, 0>(mode, z3, policy);
+    return pick_mode<0, 0>(mode, z3, policy, allout);
 }
 
 }  // namespace
@@ -967,18 +1027,22 @@ Geometry plan_geometry(const uavtrack_config &cfg, int n_simd)
     return g;
 }
 
+size_t rollout_lds_bytes(const uavtrack_env *env, int policy)
+{
+    size_t lds = env->geo.lds_bytes;
+    if (policy == kPolicyActor) lds += (size_t)(env->geo.wgs / 64) * kActorLdsFloats * sizeof(float);
+    return lds;
+}
+
 hipError_t launch_rollout(const uavtrack_env *env, const StepParams &p, hipStream_t stream, int policy)
 {
     int spec = 0;
-    KernelFn fn = pick_kernel(p.N, p.M, env->cfg.reward_mode, env->cfg.dim == 3, &spec, policy);
+    const bool allout = p.obs && p.reward && p.terms && p.covered && p.done;
+    KernelFn fn = pick_kernel(p.N, p.M, env->cfg.reward_mode, env->cfg.dim == 3, &spec, policy, allout);
     const Geometry &g = env->geo;
-    size_t lds = g.lds_bytes;
     StepParams q = p;
-    if (policy == kPolicyActor) {
-        q.actor_lds_off = (int32_t)lds;
-        lds += (size_t)(g.wgs / 64) * kActorLdsFloats * sizeof(float);
-    }
-    hipLaunchKernelGGL(fn, dim3(g.groups), dim3(g.wgs), lds, stream, q);
+    if (policy == kPolicyActor) q.actor_lds_off = (int32_t)g.lds_bytes;
+    hipLaunchKernelGGL(fn, dim3(g.groups), dim3(g.wgs), rollout_lds_bytes(env, policy), stream, q);
     return hipGetLastError();
 }
 

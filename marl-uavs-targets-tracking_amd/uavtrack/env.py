@@ -166,6 +166,42 @@ class BatchedUavEnv:
                                                 self._stream()), "uavtrack_step_many")
         return dict(obs=obs, reward=reward, terms=terms, covered=covered, done=done, ep_sums=ep)
 
+    def bind_step_many(self, actions: torch.Tensor, out: Dict[str, torch.Tensor]):
+        """A zero-argument callable that issues `uavtrack_step_many(actions -> out)` on the stream current NOW, with
+        every ctypes argument built once: what a driver replays when the per-call Python of step_many (tensor checks,
+        slicing, dict building: tens of microseconds) would be a visible share of a short launch."""
+        T = int(actions.shape[0])
+        a = self._actions(actions, (T, self.B, self.N))
+        shapes = dict(obs=((T, self.B, self.N, _lib.OBS_DIM), torch.float32), reward=((T, self.B, self.N), torch.float32),
+                      terms=((T, 3, self.B, self.N), torch.float32), covered=((T, self.B), torch.int32),
+                      done=((T, self.B), torch.uint8), ep_sums=((self.B, 5), torch.float32))
+        for k, (shape, dtype) in shapes.items():
+            if out.get(k) is not None and not self._fits(out[k], shape, dtype):
+                raise ValueError(f"out[{k!r}] must be a contiguous {dtype} {shape} tensor on {self.device}")
+        if out.get("reward") is None:
+            raise ValueError("out['reward'] is required")
+        args = (self._h, C.c_int32(T), _ptr(a), _ptr(out.get("obs")), _ptr(out["reward"]), _ptr(out.get("terms")),
+                _ptr(out.get("covered")), _ptr(out.get("done")), _ptr(out.get("ep_sums")), self._stream())
+        fn, keep = self._lib.uavtrack_step_many, (a, out)
+
+        def call():
+            if fn(*args) != 0:
+                _lib.check(1, "uavtrack_step_many")
+            return keep[1]
+        return call
+
+    def bind_reset(self, seed: int, obs: torch.Tensor):
+        """Callable(episode) issuing `uavtrack_reset` into the caller's obs buffer with pre-built arguments."""
+        if not self._fits(obs, (self.B, self.N, _lib.OBS_DIM), torch.float32):
+            raise ValueError("obs must be a contiguous float32 [B, N, 12] tensor on this device")
+        h, fn, s64, optr, st = self._h, self._lib.uavtrack_reset, C.c_uint64(seed & (2 ** 64 - 1)), _ptr(obs), self._stream()
+
+        def call(episode: int):
+            if fn(h, s64, C.c_uint32(episode), optr, st) != 0:
+                _lib.check(1, "uavtrack_reset")
+            return obs
+        return call
+
     # -- state injection / checkpoint -------------------------------------------------
     def get_state(self) -> Dict[str, torch.Tensor]:
         three = self.cfg.dim == 3

@@ -10,13 +10,14 @@ int arrays.  Nothing of the reference's source travels: the fixtures are data.
 
 Scenarios:
   g1  N5  M3   coop 0            1 seed  x 200 steps   (BASELINE configs[0])
-  g2  N20 M10  coop 0   (MAAC)   4 seeds x 30 steps
-  g3  N20 M10  coop .3  (MAAC-G) 4 seeds x 30 steps
-  g4  N20 M10  coop .3  PMI H128 4 seeds x 30 steps   (MAAC-R)
-  g5a N50 M25  coop 0            3 seeds x 12 steps
-  g5b N50 M25  coop .3  PMI      3 seeds x 12 steps
+  g2  N20 M10  coop 0   (MAAC)   8 seeds x 50 steps
+  g3  N20 M10  coop .3  (MAAC-G) 8 seeds x 50 steps
+  g4  N20 M10  coop .3  PMI H128 8 seeds x 50 steps   (MAAC-R)
+  g5a N50 M25  coop 0            4 seeds x 25 steps
+  g5b N50 M25  coop .3  PMI      4 seeds x 25 steps
   g6  reset-only layouts N in {5,10,20,50}
   g7  hand-placed edge cases (walls, wraps, inclusive/strict thresholds, ...)
+  greedy  UAV.get_action_by_direction (uav.py:324-369, the C-METHOD baseline): best_angle per UAV on recorded states
 """
 import contextlib
 import io
@@ -240,23 +241,72 @@ def gen_actor():
          dict(hidden=128, na=12, torch_seed=7, source="FnnPolicyNet(12,128,12), fc2.weight x6, fc2.bias U(-1,1)"))
 
 
+def gen_greedy():
+    """UAV.get_action_by_direction (uav.py:324-369).  Upstream it ends in a call to an undefined
+    find_closest_a_idx (uav.py:368), so the method cannot return; what it computes up to that call can be
+    recorded: a recorder is attached to the imported class under that name (it receives best_angle) and
+    random.random is pinned to 0.99 for the call, which takes the non-epsilon (uav.py:338) and the
+    non-keep-straight (uav.py:365) branch -- the deterministic target-scoring rule of uav.py:341-362.
+    States: free-running N20 M10 episodes in the reference box, and N10 M10 in a 600 m box (targets crowded
+    by several UAVs within dc: the 0.8 penalties decide)."""
+    from agent.uav import UAV  # noqa: E402  (reference)
+    seen = []
+    UAV.find_closest_a_idx = lambda self, angle: (seen.append(float(angle)), 0)[1]
+    arrays, meta = {}, {}
+    for tag, n, m, box, seeds, every in (("n20m10", 20, 10, 2000, (42, 43, 44, 45), 10), ("n10m10_box600", 10, 10, 600, (7, 8, 9, 10), 6)):
+        cfg = make_cfg(n, m, 0, x_max=box, y_max=box)
+        states, angles = [], []
+        for sd in seeds:
+            env = Environment(n_uav=n, m_targets=m, x_max=box, y_max=box, na=12)
+            random.seed(sd)
+            env.reset(config=cfg)
+            for t in range(41):
+                if t % every == 0:
+                    real = random.random
+                    random.random = lambda: 0.99
+                    try:
+                        row = []
+                        for u in env.uav_list:
+                            del seen[:]
+                            u.get_action_by_direction(env.target_list, env.uav_list)
+                            assert len(seen) == 1
+                            row.append(seen[0])
+                    finally:
+                        random.random = real
+                    states.append(snap(env))
+                    angles.append(row)
+                with contextlib.redirect_stdout(io.StringIO()):
+                    env.step(cfg, None, [random.randint(0, 11) for _ in range(n)])
+        for k in states[0]:
+            arrays[f"{tag}__{k}"] = np.array([st[k] for st in states], dtype=(np.int64 if k == "ua" else np.float64))
+        arrays[f"{tag}__best_angle"] = np.array(angles, dtype=np.float64)
+        meta[tag] = dict(n_uav=n, m_targets=m, box=box, seeds=list(seeds), states=len(states), cfg=cfg)
+    del UAV.find_closest_a_idx
+    save("greedy_ref", arrays, meta)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--only-actor":
         gen_actor()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-greedy":
+        gen_greedy()
         return
     pmi = make_pmi(128, 42)
     sd = {k: v.detach().numpy().astype(np.float32) for k, v in pmi.state_dict().items()
           if "num_batches_tracked" not in k}
     save("pmi_h128", sd, dict(hidden=128, bn_eps=1e-5, torch_seed=42))
     scenario("g1_n5m3_raw", 5, 3, 0, None, [42], 200)
-    scenario("g2_n20m10_raw", 20, 10, 0, None, [42, 43, 44, 45], 30)
-    scenario("g3_n20m10_mean", 20, 10, 0.3, None, [42, 43, 44, 45], 30)
-    scenario("g4_n20m10_pmi", 20, 10, 0.3, pmi, [42, 43, 44, 45], 30)
-    scenario("g5a_n50m25_raw", 50, 25, 0, None, [42, 43, 44], 12)
-    scenario("g5b_n50m25_pmi", 50, 25, 0.3, pmi, [42, 43, 44], 12)
+    s8 = [42, 43, 44, 45, 46, 47, 48, 49]
+    scenario("g2_n20m10_raw", 20, 10, 0, None, s8, 50)
+    scenario("g3_n20m10_mean", 20, 10, 0.3, None, s8, 50)
+    scenario("g4_n20m10_pmi", 20, 10, 0.3, pmi, s8, 50)
+    scenario("g5a_n50m25_raw", 50, 25, 0, None, [42, 43, 44, 45], 25)
+    scenario("g5b_n50m25_pmi", 50, 25, 0.3, pmi, [42, 43, 44, 45], 25)
     gen_reset()
     gen_edges(pmi)
     gen_actor()
+    gen_greedy()
 
 
 if __name__ == "__main__":

@@ -223,20 +223,22 @@ class OracleEnv:
         return dict(obs=obs, reward=reward, terms=terms, raw=raw, covered=covered, margin=margin)
 
 
-def greedy_actions(env: "OracleEnv", seed: int, step_count, env_offset: int = 0):
-    """uav.py:324-369 on the oracle env's current state -> (actions[B,N], margins dict)."""
+def greedy_actions(env: "OracleEnv", seed: int, step_count, env_offset: int = 0, force_argmax: bool = False):
+    """uav.py:324-369 on the oracle env's current state -> (actions[B,N], aids dict: margins, best_angle, branch)."""
     cfg = env.cfg
     B, N = cfg.n_envs, cfg.n_uav
     sc = np.ascontiguousarray(np.asarray(step_count, dtype=np.int32).reshape(B))
     act = np.empty((B, N), dtype=np.int32)
     ms, ma, md = np.empty((B, N)), np.empty((B, N)), np.empty(B)      # per-UAV score / angle margins, per-env |d - dc|
+    ang = np.empty((B, N))
+    branch = np.empty((B, N), dtype=np.int32)
     c = cfg.c_struct()
     rc = lib().orc_greedy_actions(C.byref(c), C.c_uint64(seed), C.c_int64(env_offset), _ip(sc),
                                   _dp(env.ux), _dp(env.uy), _dp(env.uh), _dp(env.tx), _dp(env.ty),
-                                  _ip(act), _dp(ms), _dp(ma), _dp(md))
+                                  _ip(act), _dp(ms), _dp(ma), _dp(md), C.c_int(1 if force_argmax else 0), _dp(ang), _ip(branch))
     if rc != 0:
         raise RuntimeError(f"orc_greedy_actions failed: {rc}")
-    return act, dict(score=ms, angle=ma, dist=md)
+    return act, dict(score=ms, angle=ma, dist=md, best_angle=ang, branch=branch)
 
 
 def actor_actions(cfg: OracleConfig, obs, state_dict, seed: int, step_count, mode: int = 0, env_offset: int = 0):

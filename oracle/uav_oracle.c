@@ -486,7 +486,8 @@ int orc_reset_philox(const orc_config *cfg, uint64_t seed, uint32_t episode,
 int orc_greedy_actions(const orc_config *cfg, uint64_t seed, int64_t env_offset, const int32_t *step_count,
                        const double *ux, const double *uy, const double *uh,
                        const double *tx, const double *ty,
-                       int32_t *actions, double *mg_score, double *mg_angle, double *mg_dist)
+                       int32_t *actions, double *mg_score, double *mg_angle, double *mg_dist,
+                       int force_argmax, double *best_angle_out, int32_t *branch_out)
 {
     const int B = cfg->n_envs, N = cfg->n_uav, M = cfg->m_targets, na = cfg->na;
     const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
@@ -506,7 +507,9 @@ int orc_greedy_actions(const orc_config *cfg, uint64_t seed, int64_t env_offset,
             orc_philox4x32_10(ctr, key, r);
             if (mg_score) mg_score[(size_t)b * N + i] = INFINITY;
             if (mg_angle) mg_angle[(size_t)b * N + i] = INFINITY;
-            if (u01f(r[0]) < 0.25f) {                               /* uav.py:338-339 */
+            if (best_angle_out) best_angle_out[(size_t)b * N + i] = NAN;
+            if (branch_out) branch_out[(size_t)b * N + i] = 0;
+            if (!force_argmax && u01f(r[0]) < 0.25f) {              /* uav.py:338-339 */
                 actions[(size_t)b * N + i] = (int32_t)(((uint64_t)r[1] * (uint32_t)na) >> 32);
                 continue;
             }
@@ -530,7 +533,9 @@ int orc_greedy_actions(const orc_config *cfg, uint64_t seed, int64_t env_offset,
                 }
             }
             if (best - second < ms) ms = best - second;
-            const int straight = u01f(r[2]) < 0.3f;                 /* uav.py:365-366 */
+            if (best_angle_out) best_angle_out[(size_t)b * N + i] = best_angle;   /* what uav.py:362 leaves behind */
+            const int straight = !force_argmax && u01f(r[2]) < 0.3f; /* uav.py:365-366 */
+            if (branch_out) branch_out[(size_t)b * N + i] = straight ? 1 : 2;
             if (straight) best_angle = 0.0;
             {   /* find_closest_a_idx, defined here: nearest turn rate of uav.py:73-81 to the wrapped angle */
                 const double ang = py_fmod_pos(best_angle + ORC_PI, 2.0 * ORC_PI) - ORC_PI;

@@ -9,6 +9,8 @@ are discontinuous: an environment whose fp64 margin |d - threshold| is below 1e-
 step may legitimately flip in fp32, so such environments are excluded per step (and
 counted -- they must stay rare).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -42,12 +44,32 @@ def inject(orc, st):
                   uz=st.get("uz"), tz=st.get("tz"))
 
 
-def compare_step(env, orc, act, what, margin=MARGIN, min_ok_frac=0.85):
+class Tally:
+    """Knife-edge bookkeeping of one test: env-steps set aside (fp64 margin below MARGIN) over env-steps compared.
+    `check()` bounds the rate from ABOVE -- an exclusion that grew would hide real differences."""
+
+    def __init__(self):
+        self.excluded = self.total = 0
+
+    def add(self, ok):
+        self.excluded += int((~ok).sum())
+        self.total += len(ok)
+
+    def check(self, what, max_rate=0.03, min_total=150):
+        if self.total >= min_total:          # (a handful of environments quantises the rate too coarsely to bound)
+            assert self.excluded <= max_rate * self.total, f"{what}: {self.excluded} of {self.total} env-steps on a knife edge"
+
+
+def compare_step(env, orc, act, what, margin=MARGIN, min_ok_frac=0.9, tally=None):
     """One teacher-forced step: oracle starts from the device's fp32 state."""
     inject(orc, host(env.get_state()))
     obs, rew, _ = env.step(torch.from_numpy(act))
     ref = orc.step(act)
     ok = ref["margin"] > margin
+    if os.environ.get("UAVTRACK_TEST_REPORT"):
+        print(f"[knife-edge] {what}: excluded {int((~ok).sum())}/{len(ok)} = {1 - ok.mean():.4f}", flush=True)
+    if tally is not None:
+        tally.add(ok)
     if len(ok) >= 30:
         assert ok.mean() >= min_ok_frac, f"{what}: too many knife-edge envs ({ok.mean():.3f})"
     assert ok.any(), what
@@ -81,9 +103,11 @@ def test_step_teacher_forced_vs_oracle(uavtrack, N, M, coop, B):
     env.reset(seed=1234)
     orc = OracleEnv(OracleConfig(n_envs=B, n_uav=N, m_targets=M, cooperative=coop), n_threads=8)
     rng = np.random.RandomState(N * 100 + M)
+    tally = Tally()
     for t in range(6):
         act = rng.randint(0, 12, size=(B, N)).astype(np.int32)
-        compare_step(env, orc, act, f"N{N} M{M} coop{coop} t{t}")
+        compare_step(env, orc, act, f"N{N} M{M} coop{coop} t{t}", tally=tally)
+    tally.check(f"N{N} M{M} coop{coop}")
     env.close()
 
 
@@ -101,9 +125,11 @@ def test_3d_step_teacher_forced_vs_oracle(uavtrack, N, M, coop, B):
     for k in ("ux", "uy", "uz", "uh", "tx", "ty", "tz", "th"):
         np.testing.assert_array_equal(st[k].astype(np.float64), rs[k], err_msg=f"3-D reset {k}")
     rng = np.random.RandomState(5)
+    tally = Tally()
     for t in range(8):
         act = rng.randint(0, 36, size=(B, N)).astype(np.int32)
-        compare_step(env, orc, act, f"3D N{N} M{M} t{t}")
+        compare_step(env, orc, act, f"3D N{N} M{M} t{t}", tally=tally)
+    tally.check(f"3D N{N} M{M}")
     assert np.abs(host(env.get_state())["uz"] - 150.0).max() > 1.0      # climbing really happened
 
 
@@ -157,9 +183,11 @@ def test_pmi_reward_teacher_forced_vs_oracle(uavtrack, pmi_state_dict, N, M, B, 
     orc.pmi = OraclePmi.from_state_dict(sd)
     rng = np.random.RandomState(8)
     saw_pairs = 0
+    tally = Tally()
     for t in range(5):
         act = rng.randint(0, 12, size=(B, N)).astype(np.int32)
-        compare_step(env, orc, act, f"PMI N{N} H{hidden} t{t}", min_ok_frac=0.5)
+        compare_step(env, orc, act, f"PMI N{N} H{hidden} t{t}", tally=tally)
+    tally.check(f"PMI N{N} H{hidden}")
         saw_pairs += int((np.abs(env.info["terms"].cpu().numpy()[2]) > 0.04).sum())
     assert saw_pairs > 0       # neighbours existed, so the network really ran
 
@@ -246,9 +274,11 @@ def test_dense_box_many_neighbours(uavtrack):
     env.reset(seed=7)
     orc = OracleEnv(OracleConfig(**kw), n_threads=8)
     rng = np.random.RandomState(3)
+    tally = Tally()
     for t in range(25):
         act = rng.randint(0, 12, size=(128, 20)).astype(np.int32)
-        compare_step(env, orc, act, f"dense t{t}", min_ok_frac=0.5)
+        compare_step(env, orc, act, f"dense t{t}", tally=tally)
+    tally.check("dense box", max_rate=0.02)
 
 
 def test_reset_bitexact_vs_oracle_and_first_obs(uavtrack):
@@ -286,12 +316,21 @@ def test_against_reference_goldens(uavtrack, name):
     # margins from the oracle started at the same fp32-rounded state
     orc = OracleEnv(OracleConfig(n_envs=B, n_uav=N, m_targets=M, cooperative=coop), n_threads=8)
     inject(orc, host(env.get_state()))
-    ok = orc.step(act)["margin"] > 5e-3
-    assert ok.mean() > 0.9
+    ref = orc.step(act)
+    ok = ref["margin"] > 5e-3            # (wider than MARGIN: the golden's own fp64 state differs from the injected fp32 one)
+    if os.environ.get("UAVTRACK_TEST_REPORT"):
+        print(f"[knife-edge] golden {name}: excluded {int((~ok).sum())}/{B} = {1 - ok.mean():.4f}", flush=True)
+    assert ok.mean() >= 0.93, f"{name}: {1 - ok.mean():.3f} of the golden env-steps within 5 mm of a threshold"
     obs, rew, _ = env.step(torch.from_numpy(act))
     obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
     terms, cov = env.info["terms"].cpu().numpy(), env.info["covered"].cpu().numpy()
-    # inputs were rounded to fp32 (<= 6e-5 m on a pose), hence 2e-5 rather than 1e-5 here
+    # (1) north_star's 1e-5 against the oracle restarted from the SAME fp32 state the kernel stepped from ...
+    np.testing.assert_allclose(obs[ok], ref["obs"][ok], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(rew[ok], ref["reward"][ok], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(terms[:, ok], ref["terms"][:, ok], rtol=0, atol=ATOL)
+    np.testing.assert_array_equal(cov[ok], ref["covered"][ok])
+    # (2) ... and the reference's own recorded outputs at 2e-5: the golden stepped from fp64 poses, the injected state
+    # is their fp32 rounding (up to 6e-5 m on a pose at 2000 m), which alone moves a normalised output by ~1e-5
     np.testing.assert_allclose(obs[ok], z["obs"].reshape(B, N, 12)[ok], rtol=0, atol=2e-5)
     np.testing.assert_allclose(rew[ok], z["reward"].reshape(B, N)[ok], rtol=0, atol=2e-5)
     np.testing.assert_allclose(terms[:, ok], np.moveaxis(z["terms"].reshape(B, 3, N), 1, 0)[:, ok], rtol=0, atol=2e-5)
@@ -408,6 +447,78 @@ def test_full_size_properties_and_shard_equivalence(uavtrack):
             sl = out[k][:, :, off:off + cnt] if k == "terms" else out[k][:, off:off + cnt]
             assert torch.equal(o2[k], sl), (rank, k)
         assert torch.equal(o2["ep_sums"], out["ep_sums"][off:off + cnt])
+
+
+BASELINE_SHAPES = [
+    # BASELINE.json configs[1], [2], [3] at their stated sizes
+    ("c1_4096x20x10_raw", dict(n_envs=4096, n_uav=20, m_targets=10, cooperative=0.0), False, 8),
+    ("c2_4096x20x10_pmi", dict(n_envs=4096, n_uav=20, m_targets=10, cooperative=0.3), True, 6),
+    ("c3_8192x50x25_3d", dict(n_envs=8192, n_uav=50, m_targets=25, cooperative=0.0, dim=3, nc=3, z_max=300.0), False, 5),
+]
+
+
+@pytest.mark.parametrize("name,kw,pmi,steps", BASELINE_SHAPES, ids=[c[0] for c in BASELINE_SHAPES])
+def test_baseline_shapes_full_size(uavtrack, pmi_state_dict, name, kw, pmi, steps):
+    """The three single-GPU BASELINE configurations at FULL size (environment.py:120-164 outputs): size-independent
+    properties over every environment of the batch, and a teacher-forced comparison with the fp64 oracle on a random
+    128-environment subset gathered from the full batch at every step (the bounded soak).  The knife-edge exclusion
+    (an fp64 range-test margin below 1e-3 m in that step) is bounded from above: at most 1 % of the compared
+    env-steps may be set aside, and indices (coverage counts, actions) are exact on all the others."""
+    from oracle import OraclePmi
+    B, N, M = kw["n_envs"], kw["n_uav"], kw["m_targets"]
+    na = 12 * kw.get("nc", 1)
+    mode = uavtrack.RewardMode.PMI if pmi else None
+    env = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(reward_mode=mode, horizon=steps, **kw))
+    if pmi:
+        env.set_pmi(pmi_state_dict)
+    env.reset(seed=2026)
+    S = 128
+    rng = np.random.RandomState(len(name))
+    subset = np.sort(rng.choice(B, S, replace=False))
+    sub_t = torch.from_numpy(subset).cuda()
+    okw = dict(kw, n_envs=S)
+    orc = OracleEnv(OracleConfig(**okw), n_threads=8)
+    if pmi:
+        orc.pmi = OraclePmi.from_state_dict(pmi_state_dict)
+    gen = torch.Generator("cuda").manual_seed(7)
+    compared = excluded = 0
+    worst = dict(obs=0.0, reward=0.0, terms=0.0)
+    for t in range(steps):
+        st = env.get_state()
+        inject(orc, {k: v[sub_t].cpu().numpy() for k, v in st.items() if k != "step_count"})
+        act = torch.randint(0, na, (B, N), dtype=torch.int32, device="cuda", generator=gen)
+        obs, rew, done = env.step(act)
+        terms, cov = env.info["terms"], env.info["covered"]
+        # ---- properties, every environment
+        assert torch.isfinite(obs).all() and torch.isfinite(rew).all(), name
+        assert rew.abs().max() <= 1.0
+        assert terms[0].min() >= 0 and terms[0].max() <= 1 and terms[1].min() >= -1 and terms[1].max() <= 0
+        assert terms[2].min() >= -1 and terms[2].max() <= 0
+        assert cov.min() >= 0 and cov.max() <= M
+        assert torch.equal(torch.round(obs[..., 11] * na).int(), act)        # a / Na carries the action index
+        assert bool(done.all()) == (t == steps - 1) and bool(done.any()) == (t == steps - 1)
+        # ---- oracle on the subset
+        ref = orc.step(act[sub_t].cpu().numpy())
+        ok = ref["margin"] > MARGIN
+        compared += S
+        excluded += int((~ok).sum())
+        o, r = obs[sub_t].cpu().numpy(), rew[sub_t].cpu().numpy()
+        tm, cv = terms[:, sub_t].cpu().numpy(), cov[sub_t].cpu().numpy()
+        np.testing.assert_allclose(o[ok], ref["obs"][ok], rtol=0, atol=ATOL, err_msg=f"{name} t{t} obs")
+        np.testing.assert_allclose(r[ok], ref["reward"][ok], rtol=0, atol=ATOL, err_msg=f"{name} t{t} reward")
+        np.testing.assert_allclose(tm[:, ok], ref["terms"][:, ok], rtol=0, atol=ATOL, err_msg=f"{name} t{t} terms")
+        np.testing.assert_array_equal(cv[ok], ref["covered"][ok], err_msg=f"{name} t{t} covered")
+        worst["obs"] = max(worst["obs"], float(np.abs(o - ref["obs"])[ok].max()))
+        worst["reward"] = max(worst["reward"], float(np.abs(r - ref["reward"])[ok].max()))
+        worst["terms"] = max(worst["terms"], float(np.abs(tm - ref["terms"])[:, ok].max()))
+        # poses after the step
+        st2, rs = env.get_state(), orc.get_state()
+        for k in ("ux", "uy", "tx", "ty") + (("uz",) if "uz" in st2 else ()):
+            np.testing.assert_allclose(st2[k][sub_t].cpu().numpy(), rs[k], rtol=RTOL_POSE, atol=1e-4, err_msg=f"{name} t{t} {k}")
+        assert ang_diff(st2["uh"][sub_t].cpu().numpy(), rs["uh"]).max() < 1e-5
+    assert excluded <= 0.01 * compared, f"{name}: {excluded} of {compared} env-steps on a knife edge (> 1 %)"
+    assert int(env.get_state()["step_count"].min()) == steps
+    env.close()
 
 
 def test_compat_environment_reference_call_shapes(uavtrack):
@@ -534,6 +645,38 @@ def test_greedy_baseline_policy_vs_oracle(uavtrack):
         res[mode] = ro.run(17)["ep_sums"].clone()
     assert torch.equal(res[False], res[True])
     assert res[True][:, 1].sum() > 0          # the baseline does find targets
+
+
+def test_greedy_policy_vs_reference_best_angle(uavtrack):
+    """uavtrack_greedy_actions against the REFERENCE's own target scoring (tests/golden/greedy_ref.npz: best_angle
+    recorded from UAV.get_action_by_direction, uav.py:324-362, in the build container).  Wherever the kernel's
+    Philox draws select the scoring branch (the oracle, bit-exact on those draws, says which UAVs), the action must
+    be the defined nearest-turn-rate index of the reference's angle; fp32 leaves no room within the angle margin."""
+    from oracle import greedy_actions
+    from test_oracle_golden import closest_action
+    z, meta = load_golden("greedy_ref")
+    checked = 0
+    for tag, m in meta.items():
+        N, M, S = m["n_uav"], m["m_targets"], m["states"]
+        kw = dict(n_envs=S, n_uav=N, m_targets=M, x_max=float(m["box"]), y_max=float(m["box"]))
+        env = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(**kw))
+        orc = OracleEnv(OracleConfig(**kw))
+        st = {k: z[f"{tag}__{k}"] for k in ("ux", "uy", "uh", "ua", "tx", "ty", "th")}
+        env.set_state(**st)
+        st32 = host(env.get_state())
+        inject(orc, st32)                                       # the oracle's margins on the fp32 state the kernel sees
+        idx, near = closest_action(z[f"{tag}__best_angle"])
+        for seed in (5, 6, 7, 8):
+            got = env.greedy_actions(seed=seed).cpu().numpy()
+            _, aid = greedy_actions(orc, seed, np.zeros(S, np.int32))
+            sel = (aid["branch"] == 2) & (near[..., 1] - near[..., 0] > 2e-3) & (aid["score"] > 2e-5) & (aid["dist"][:, None] > 1e-2)
+            assert sel.mean() > 0.35, (tag, seed, sel.mean())
+            np.testing.assert_array_equal(got[sel], idx[sel], err_msg=f"{tag} seed {seed}")
+            straight = aid["branch"] == 1
+            assert (got[straight] == 5).all()                   # keep-straight: angle 0 -> the lower middle action
+            checked += int(sel.sum())
+        env.close()
+    assert checked > 1000
 
 
 def golden_actor():

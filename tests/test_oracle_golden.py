@@ -156,6 +156,53 @@ def test_greedy_policy_restatement_semantics():
     assert counts[0] > 120 and counts[1] < 30
 
 
+def closest_action(angle, na=12, turn_unit=np.pi / 6 / 11):
+    """find_closest_a_idx as DEFINED in include/uavtrack.h (the reference leaves it undefined, uav.py:368): the turn rate
+    (2a + 1 - na) * dt * h_max / (na - 1) of uav.py:73-81 nearest to the wrapped angle, lowest index on ties."""
+    ang = (angle + np.pi) % (2 * np.pi) - np.pi
+    w = (2 * np.arange(na) + 1 - na) * turn_unit
+    d = np.abs(ang[..., None] - w)
+    return d.argmin(-1).astype(np.int32), np.sort(d, -1)[..., :2]
+
+
+def test_greedy_restatement_pinned_by_reference_best_angle():
+    """The reference's own UAV.get_action_by_direction (uav.py:324-369) was run in the build container with a
+    recorder attached as the missing find_closest_a_idx and random.random pinned past both random branches
+    (oracle/gen_golden.py gen_greedy): `best_angle` per UAV on 40 recorded states.  The oracle's target scoring
+    (1/d - 0.8 per other UAV within dc, first best, atan2 - heading) must reproduce it, and its action is the
+    defined nearest-turn-rate index of that angle."""
+    from oracle import greedy_actions
+    z, meta = load_golden("greedy_ref")
+    for tag, m in meta.items():
+        N, M, S = m["n_uav"], m["m_targets"], m["states"]
+        orc = OracleEnv(OracleConfig(n_envs=S, n_uav=N, m_targets=M, x_max=m["box"], y_max=m["box"]))
+        orc.set_state(*[z[f"{tag}__{k}"] for k in ("ux", "uy", "uh", "ua", "tx", "ty", "th")])
+        act, aid = greedy_actions(orc, 0, np.zeros(S, np.int32), force_argmax=True)
+        want = z[f"{tag}__best_angle"]
+        assert want.shape == (S, N)
+        np.testing.assert_allclose(aid["best_angle"], want, rtol=0, atol=1e-12)
+        assert (aid["branch"] == 2).all()
+        idx, near = closest_action(want)
+        clear = near[..., 1] - near[..., 0] > 1e-9          # (angle 0 is an exact tie between the two middle actions)
+        np.testing.assert_array_equal(act[clear], idx[clear])
+        assert clear.mean() > 0.95
+        # the unforced policy takes the same decision wherever its draws select the scoring branch
+        for seed in (1, 2, 3):
+            a2, aid2 = greedy_actions(orc, seed, np.zeros(S, np.int32))
+            sel = (aid2["branch"] == 2) & clear
+            assert 0.4 < (aid2["branch"] == 2).mean() < 0.65            # 0.75 * 0.7
+            np.testing.assert_array_equal(a2[sel], idx[sel])
+            np.testing.assert_allclose(aid2["best_angle"][aid2["branch"] > 0], want[aid2["branch"] > 0], rtol=0, atol=1e-12)
+    # the crowded box is where the 0.8 penalties decide: the nearest target must NOT always win there
+    tag = "n10m10_box600"
+    d = np.hypot(z[f"{tag}__tx"][:, None, :] - z[f"{tag}__ux"][:, :, None], z[f"{tag}__ty"][:, None, :] - z[f"{tag}__uy"][:, :, None])
+    nearest = d.argmin(-1)
+    k = np.arange(d.shape[1])
+    ang_nearest = np.arctan2(np.take_along_axis(z[f"{tag}__ty"][:, None, :].repeat(d.shape[1], 1), nearest[..., None], -1)[..., 0] - z[f"{tag}__uy"],
+                             np.take_along_axis(z[f"{tag}__tx"][:, None, :].repeat(d.shape[1], 1), nearest[..., None], -1)[..., 0] - z[f"{tag}__ux"]) - z[f"{tag}__uh"]
+    assert (np.abs(ang_nearest - z[f"{tag}__best_angle"]) > 1e-6).mean() > 0.1
+
+
 def test_actor_restatement_matches_reference_network():
     """oracle.actor_actions (fp64) against probabilities recorded from the reference's own FnnPolicyNet
     (actor_critic.py:85-98, torch fp32) -- golden actor_h128, generated by oracle/gen_golden.py."""

@@ -93,21 +93,21 @@ __global__ void __launch_bounds__(64) bench(float *out, unsigned long long *tick
 }
 
 template <int TEST>
-int run(const char *name, int per_iter, int grid)
+int run(const char *name, int per_iter, int grid, int lanes = 64)
 {
     float *out; unsigned long long *ticks;
     CHK(hipMalloc(&out, (size_t)grid * 64 * 4)); CHK(hipMalloc(&ticks, (size_t)grid * 8));
     const int iters = 2000;
-    hipLaunchKernelGGL(bench<TEST>, dim3(grid), dim3(64), 0, 0, out, ticks, 10);
+    hipLaunchKernelGGL(bench<TEST>, dim3(grid), dim3(lanes), 0, 0, out, ticks, 10);
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     CHK(hipEventRecord(e0));
-    hipLaunchKernelGGL(bench<TEST>, dim3(grid), dim3(64), 0, 0, out, ticks, iters);
+    hipLaunchKernelGGL(bench<TEST>, dim3(grid), dim3(lanes), 0, 0, out, ticks, iters);
     CHK(hipEventRecord(e1)); CHK(hipDeviceSynchronize());
     float ms = 0; CHK(hipEventElapsedTime(&ms, e0, e1));
     std::vector<unsigned long long> h(grid);
     CHK(hipMemcpy(h.data(), ticks, (size_t)grid * 8, hipMemcpyDeviceToHost));
     double s = 0; for (auto v : h) s += (double)v;
-    printf("%-52s grid %5d: %7.2f ticks/instr (s_memtime), %7.2f ns/instr wall\n", name, grid, s / grid / iters / per_iter, ms * 1e6 / iters / per_iter);
+    printf("%-52s grid %5d lanes %2d: %7.2f ticks/instr (s_memtime), %7.2f ns/instr wall\n", name, grid, lanes, s / grid / iters / per_iter, ms * 1e6 / iters / per_iter);
     CHK(hipFree(out)); CHK(hipFree(ticks));
     return 0;
 }
@@ -132,5 +132,13 @@ int main()
         run<13>("alternating s_add_u32 / v_fma_f32", 64, grid);
         run<14>("v_readlane -> s_add pairs, per instruction", 64, grid);
     }
+    // Is the second 32-lane pass of a wave64 instruction skipped when EXEC[63:32] == 0?  Same loops, 32 and 20 active lanes.
+    for (int lanes : {64, 32, 20})
+        for (int grid : {4096, 8192}) {
+            run<0>("8 independent v_pk_fma_f32", 64, grid, lanes);
+            run<2>("8 independent v_fma_f32", 64, grid, lanes);
+            run<4>("8 independent v_sqrt_f32", 64, grid, lanes);
+            run<7>("8 ds_read_b128 + one wait (per read)", 8, grid, lanes);
+        }
     return 0;
 }
