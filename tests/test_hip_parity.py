@@ -187,8 +187,8 @@ def test_pmi_reward_teacher_forced_vs_oracle(uavtrack, pmi_state_dict, N, M, B, 
     for t in range(5):
         act = rng.randint(0, 12, size=(B, N)).astype(np.int32)
         compare_step(env, orc, act, f"PMI N{N} H{hidden} t{t}", tally=tally)
-    tally.check(f"PMI N{N} H{hidden}")
         saw_pairs += int((np.abs(env.info["terms"].cpu().numpy()[2]) > 0.04).sum())
+    tally.check(f"PMI N{N} H{hidden}")
     assert saw_pairs > 0       # neighbours existed, so the network really ran
 
 
