@@ -71,7 +71,7 @@ hipError_t dmalloc(T **p, size_t n)
 
 void free_state(uavtrack_env *env)
 {
-    void *ptrs[] = {env->slab, env->pmi.blob, env->actor_w, env->pairs, env->pair_count, env->pair_total, env->scores, env->pose,
+    void *ptrs[] = {env->slab, env->pmi.blob, env->actor_w, env->pairs, env->pair_count, env->pair_total, env->scores, env->nbrec,
                     env->obs_tmp, env->terms_tmp, env->covered_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -102,14 +102,15 @@ int validate(const uavtrack_config &c)
 }
 
 // MAAC-R scratch for deferred scoring of up to `steps` steps per chunk (grow-only).  Per step: the pair
-// list at its worst case (every pair within dp), the dense score matrix, pose/raw, and observation /
+// list and its score array at their worst case (every pair within dp), the neighbour records, and observation /
 // term buffers for callers that pass NULL.  UAVTRACK_PMI_SCRATCH_MB bounds it (default 2048 MiB).
 int ensure_pmi_scratch(uavtrack_env *env, int32_t steps, hipStream_t st)
 {
     const uavtrack_config &c = env->cfg;
     const size_t BN = (size_t)c.n_envs * c.n_uav;
     const size_t pairs_step = BN * (c.n_uav - 1) / 2 + 1;
-    const size_t per_step = pairs_step * sizeof(uint2) + BN * c.n_uav * 4 + BN * 16 + BN * UAVTRACK_OBS_DIM * 4 + 3 * BN * 4 +
+    const size_t rec_bytes = (size_t)nbrec_words(c.n_uav) * 4;
+    const size_t per_step = pairs_step * (sizeof(uint2) + 4) + BN * rec_bytes + BN * UAVTRACK_OBS_DIM * 4 + 3 * BN * 4 +
                             (size_t)c.n_envs * 4;
     size_t budget = (size_t)2048 << 20;
     if (const char *s = getenv("UAVTRACK_PMI_SCRATCH_MB")) budget = (size_t)atoll(s) << 20;
@@ -120,16 +121,16 @@ int ensure_pmi_scratch(uavtrack_env *env, int32_t steps, hipStream_t st)
     if (cap > steps) cap = steps;
     if (cap <= env->pmi_steps_cap) return 0;
     HIP_TRY(hipStreamSynchronize(st));
-    void *old[] = {env->pairs, env->scores, env->pose, env->obs_tmp, env->terms_tmp, env->covered_tmp};
+    void *old[] = {env->pairs, env->scores, env->nbrec, env->obs_tmp, env->terms_tmp, env->covered_tmp};
     for (void *q : old)
         if (q) (void)hipFree(q);
-    env->pairs = nullptr; env->scores = nullptr; env->pose = nullptr; env->obs_tmp = nullptr; env->terms_tmp = nullptr;
+    env->pairs = nullptr; env->scores = nullptr; env->nbrec = nullptr; env->obs_tmp = nullptr; env->terms_tmp = nullptr;
     env->covered_tmp = nullptr;
     env->pmi_steps_cap = 0;
     const size_t S = (size_t)cap;
     HIP_TRY(dmalloc(&env->pairs, S * pairs_step));
-    HIP_TRY(dmalloc(&env->scores, S * BN * c.n_uav));
-    HIP_TRY(dmalloc(&env->pose, S * BN));
+    HIP_TRY(dmalloc(&env->scores, S * pairs_step));
+    HIP_TRY(dmalloc(&env->nbrec, S * BN * nbrec_words(c.n_uav)));
     HIP_TRY(dmalloc(&env->obs_tmp, S * BN * UAVTRACK_OBS_DIM));
     HIP_TRY(dmalloc(&env->terms_tmp, S * 3 * BN));
     HIP_TRY(dmalloc(&env->covered_tmp, S * (size_t)c.n_envs));
@@ -392,7 +393,7 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
     hipStream_t st = static_cast<hipStream_t>(stream);
     StepParams p = env->base;
     p.actions = actions;
-    p.obs = obs; p.reward = reward; p.terms = terms; p.pose_out = nullptr;
+    p.obs = obs; p.reward = reward; p.terms = terms; p.nbrec = nullptr;
     p.covered = covered; p.done = done; p.ep_sums = ep_sums;
     p.pairs = nullptr; p.pair_count = nullptr;
     p.ep_accumulate = accumulate ? 1 : 0;
@@ -417,7 +418,7 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
     const uavtrack_config &c = env->cfg;
     const size_t BN = (size_t)c.n_envs * c.n_uav;
     p.ep_sums = nullptr;
-    p.pose_out = env->pose;
+    p.nbrec = env->nbrec;
     p.pairs = env->pairs;
     p.pair_count = env->pair_count;      // zero: set at allocation, re-zeroed by the mix kernel
     bool add = accumulate;
@@ -481,7 +482,7 @@ int uavtrack_run_greedy(uavtrack_env *env, int32_t T, uint64_t seed, int32_t *ac
     StepParams p = env->base;
     p.T = T;
     p.actions = nullptr; p.actions_out = actions_out;
-    p.obs = obs; p.reward = reward; p.terms = terms; p.pose_out = nullptr;
+    p.obs = obs; p.reward = reward; p.terms = terms; p.nbrec = nullptr;
     p.covered = covered; p.done = done; p.ep_sums = ep_sums;
     p.pairs = nullptr; p.pair_count = nullptr; p.ep_accumulate = 0;
     p.env_offset = env->cfg.env_offset;

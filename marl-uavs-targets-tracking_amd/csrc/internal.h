@@ -57,7 +57,7 @@ struct StepParams {
     // per-step I/O, leading [T] axis
     const int32_t *actions;
     float *obs, *reward, *terms;
-    float4 *pose_out;        // MAAC-R: (x, y, z, raw reward) per agent-step, read by the deferred softmax mix
+    uint32_t *nbrec;         // MAAC-R: neighbour record per agent-step, read by the deferred softmax mix (nbrec_words())
     int32_t *covered;
     uint8_t *done;
     float *ep_sums;
@@ -90,6 +90,13 @@ struct StepParams {
     float alpha, beta, gamma, coop;
 };
 
+// MAAC-R neighbour record of one agent-step, 32-bit words: [0 .. W) neighbour bit mask (d <= dp on post-move poses,
+// uav.py:278; bit j = UAV j, self excluded), [W] index of the first pair this UAV emitted (its neighbours j > i, in
+// ascending j, occupy consecutive slots of the pair list / score array), [W + 1] raw reward (float bits).
+// W = 2 up to 64 UAVs (one 16-byte record), else ceil(N / 32).
+__host__ __device__ inline int nbrec_mask_words(int N) { return N <= 64 ? 2 : (N + 31) / 32; }
+__host__ __device__ inline int nbrec_words(int N) { return nbrec_mask_words(N) + 2; }
+
 struct PmiWeights {
     float *blob = nullptr;   // device, folded layout of uavtrack_set_pmi_weights
     int32_t hidden = 0;
@@ -117,14 +124,14 @@ struct uavtrack_env {
     int32_t actor_hidden = 0;
     // MAAC-R scratch for `pmi_steps_cap` steps of deferred scoring (rewards never feed back into the
     // dynamics, so a chunk of steps is simulated first and all its pairs are scored in one launch):
-    // pair list + counter, dense score matrix [steps][B][N][N], pose/raw [steps][B][N], and
+    // pair list + counter, one score per pair, neighbour records [steps][B][N], and
     // observation / term buffers for callers that pass NULL
     int32_t pmi_steps_cap = 0;
     uint2 *pairs = nullptr;
     unsigned *pair_count = nullptr;
     unsigned long long *pair_total = nullptr;
-    float *scores = nullptr, *obs_tmp = nullptr, *terms_tmp = nullptr;
-    float4 *pose = nullptr;
+    float *scores = nullptr, *obs_tmp = nullptr, *terms_tmp = nullptr;   // scores: one per emitted pair
+    uint32_t *nbrec = nullptr;
     int32_t *covered_tmp = nullptr;   // [steps][B] coverage counts for ep_sums when the caller passes covered = NULL
 };
 

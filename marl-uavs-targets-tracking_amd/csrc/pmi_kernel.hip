@@ -15,12 +15,14 @@
 // form x = la_i * la_j, run the three small branch layers (5/4/3 -> H, BatchNorm folded,
 // ReLU) on the VALU from LDS-resident weights and write the 32 x 3H activation tile to LDS
 // in MFMA A-operand order; then each wavefront runs 3H/2 back-to-back MFMAs reading one
-// ds_read_b128 per four of them.  Epilogue: ReLU, times fc2, fixed-order lane reduction,
-// fixed-order sum over the H/32 column blocks -> s_ij, stored at [b][i][j] and [b][j][i].
+// ds_read_b128 per four of them.  Epilogue: ReLU, times fc2, fixed-order lane reduction on the DPP paths,
+// fixed-order sum over the H/32 column blocks -> s_ij (= s_ji), stored once, in the pair's slot of the pair list.
 //
-// pmi_finalize_kernel: one thread per UAV: neighbours in index order, max-shifted softmax of
+// pmi_mix_kernel: one thread per UAV-step: neighbours in index order, max-shifted softmax of
 // their scores (scipy.special.softmax, uav.py:287), reward = (1-a) raw_i + a sum_j w_j raw_j,
-// (1-a) raw_i without neighbours (uav.py:290), final clip (environment.py:225).
+// (1-a) raw_i without neighbours (uav.py:290), final clip (environment.py:225).  It finds the
+// score of (i, j) through the neighbour records the rollout kernel wrote (internal.h: nbrec_words):
+// UAV min(i, j) emitted the pair, in the slot "its first slot + rank of max(i, j) among its later neighbours".
 
 #include "internal.h"
 
@@ -31,12 +33,31 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// Sum of a value over the 32 lanes of each wavefront half in a fixed order, on the VALU's cross-lane (DPP) paths --
+// no LDS crossbar traffic beside the MFMA operand reads.  The total of lanes 0..31 lands in lanes 16..31, that of
+// lanes 32..63 in lanes 48..63.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
+    return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float half_wave_sum(float v)
+{
+    v = dpp_add<0xB1>(v);            // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);            // quad_perm [2,3,0,1]: every lane of a quad holds the quad's sum
+    v = dpp_add<0x141>(v);           // row_half_mirror: + the other quad of the 8
+    v = dpp_add<0x140>(v);           // row_mirror: + the other 8 of the row -> every lane holds its row's 16-lane sum
+    v = dpp_add<0x142, 0xa>(v);      // row_bcast15 into rows 1 and 3: + the previous row's sum
+    return v;
+}
+
 struct PmiParams {
     const float *blob;       // folded weights, layout of uavtrack_set_pmi_weights
     const float *obs;        // [S][B][N][12] local states of the chunk's steps
     const uint2 *pairs;      // {flat [step][b][i] index of i within the chunk, j}
     const unsigned *pair_count;
-    float *scores;           // [S][B][N][N]
+    float *scores;           // one per pair, in pair-list order
     unsigned long long *pair_total;
     int32_t N;
 };
@@ -51,10 +72,11 @@ __global__ void __launch_bounds__(H * 2, 2) pmi_score_kernel(const PmiParams q)
     constexpr int NT = NW * 64;          // threads = 2 H
     constexpr int PPT = 32 / (NT / H);   // pairs per thread in the branch layers (16)
 
-    __shared__ float4 lds4[(2 * 32 * ROW + 2 * 32 * 12 + 2 * NW * 32) / 4 + 2];
+    __shared__ float4 lds4[(2 * 32 * ROW + 2 * 32 * 12 + 2 * NW * 32 + 20 * H) / 4 + 2];
     float *h0s = reinterpret_cast<float *>(lds4);          // [2][32][ROW]  (k parity, pair, k/2)
     float *xs = h0s + 2 * 32 * ROW;                        // [2 tiles][32 pairs][12]  x = la_i * la_j
     float *part = xs + 2 * 32 * 12;                        // [2 tiles][NW][32] per-column-block partial scores
+    float *bw = part + 2 * NW * 32;                        // [H][20] branch-layer weights of output o: wc[5] bc wo[4] bo wb[3] bb, pad
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -81,17 +103,23 @@ __global__ void __launch_bounds__(H * 2, 2) pmi_score_kernel(const PmiParams q)
     // Branch layers (PMINet.py:50-55): thread (o, half) owns output o of each of the three branches for
     // 16 of the tile's 32 pairs; its 15 folded weights stay in registers, only the pair inputs come
     // from LDS (three broadcast ds_read_b128 per pair).
+    // Their 15 folded weights and 3 biases per output live in LDS and are fetched at the head of every tile (five
+    // ds_read_b128): held in registers for the whole kernel they pushed the register-stationary fc1 slice into
+    // scratch spills.
     const int o = tid % H, phalf = tid / H;
-    float wc[5], wo[4], wb[3];
+    if (tid < H) {
+        float *d = bw + tid * 20;
 #pragma unroll
-    for (int v = 0; v < 5; ++v) wc[v] = q.blob[v * H + o];
-    const float bc = q.blob[5 * H + o];
+        for (int v = 0; v < 5; ++v) d[v] = q.blob[v * H + tid];
+        d[5] = q.blob[5 * H + tid];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) wo[v] = q.blob[6 * H + v * H + o];
-    const float bo = q.blob[10 * H + o];
+        for (int v = 0; v < 4; ++v) d[6 + v] = q.blob[6 * H + v * H + tid];
+        d[10] = q.blob[10 * H + tid];
 #pragma unroll
-    for (int v = 0; v < 3; ++v) wb[v] = q.blob[11 * H + v * H + o];
-    const float bb = q.blob[14 * H + o];
+        for (int v = 0; v < 3; ++v) d[11 + v] = q.blob[11 * H + v * H + tid];
+        d[14] = q.blob[14 * H + tid];
+        d[15] = d[16] = d[17] = d[18] = d[19] = 0.0f;
+    }
     // where this thread's three outputs live in the activation tile: concat order (PMINet.py:58)
     // comm | obs | boundary_state; k -> (parity k & 1, step k >> 1)
     const int k0 = o, k1 = H + o, k2 = 2 * H + o;
@@ -138,6 +166,14 @@ __global__ void __launch_bounds__(H * 2, 2) pmi_score_kernel(const PmiParams q)
     for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // ---- branch layers of this tile, from xs[cur]
         const float *xt = xs + cur * 32 * 12;
+        float wc[5], wo[4], wb[3], bc, bo, bb;
+        {
+            const float4 *wq = reinterpret_cast<const float4 *>(bw + o * 20);
+            const float4 w0 = wq[0], w1 = wq[1], w2q = wq[2], w3 = wq[3];
+            wc[0] = w0.x; wc[1] = w0.y; wc[2] = w0.z; wc[3] = w0.w; wc[4] = w1.x; bc = w1.y;
+            wo[0] = w1.z; wo[1] = w1.w; wo[2] = w2q.x; wo[3] = w2q.y; bo = w2q.z;
+            wb[0] = w2q.w; wb[1] = w3.x; wb[2] = w3.y; bb = w3.z;
+        }
 #pragma unroll 4
         for (int pp = 0; pp < PPT; ++pp) {
             const int pr_i = phalf * PPT + pp;
@@ -184,86 +220,100 @@ __global__ void __launch_bounds__(H * 2, 2) pmi_score_kernel(const PmiParams q)
         float *pc = part + cur * NW * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float v = fmaxf(acc[r], 0.0f) * wout;
-#pragma unroll
-            for (int msk = 1; msk < 32; msk <<= 1) v += __shfl_xor(v, msk, 64);
+            const float v = half_wave_sum(fmaxf(acc[r], 0.0f) * wout);
             // C/D layout of 32x32 MFMA: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-            if ((lane & 31) == 0) pc[w * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh] = v;
+            if ((lane & 31) == 16) pc[w * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh] = v;
         }
         __syncthreads();                                    // partials complete; everyone is past the MFMA reads
         if (tid < 32 && tile * 32 + tid < npairs) {
             float sc = b2;
 #pragma unroll
             for (int ww = 0; ww < NW; ++ww) sc += pc[ww * 32 + tid];
-            const unsigned gi = pr_this.x, bidx = gi / q.N, ii = gi - bidx * q.N, jj = pr_this.y;
-            q.scores[(size_t)gi * q.N + jj] = sc;
-            q.scores[((size_t)bidx * q.N + jj) * q.N + ii] = sc;
+            q.scores[tile * 32 + tid] = sc;                 // the pair's own slot: s_ij = s_ji is stored once
         }
         cur ^= 1;   // `part` and `xs` are double-buffered by tile parity: two barriers per tile suffice
     }
 }
 
-struct FinalizeParams {
-    const float4 *pose;          // [S][B][N] (x, y, z, raw) of the chunk's S steps
-    const float *scores;         // [S][B][N][N]
+struct MixParams {
+    const uint32_t *nbrec;       // [S][B][N][W + 2] neighbour records of the chunk's S steps
+    const float *scores;         // one per pair
     float *reward;               // [S][B][N]
     unsigned *pair_count;        // reset here for the next chunk's pair emission
-    int32_t SB, N, E, three_d;   // SB = S * B "virtual environments"
-    float dp2, coop;
+    int32_t SB, N, E;            // SB = S * B "virtual environments"
+    float coop;
 };
 
-// One lane per UAV-step, E whole (step, environment) instances per workgroup (the step kernel's
-// geometry over S*B instances).  Poses and raw rewards of the workgroup's instances are staged in
-// LDS; every lane walks its row of the score matrix with unconditional, independent loads.
-__global__ void __launch_bounds__(kMaxWorkgroup) pmi_finalize_kernel(const FinalizeParams f)
+// One lane per UAV-step, E whole (step, environment) instances per workgroup.  The instances' records are staged
+// in LDS; a lane walks the set bits of its own mask twice (max, then exp-sum) and reads one score per neighbour.
+template <bool SMALL>            // SMALL: N <= 64, 16-byte records, 64-bit mask arithmetic
+__global__ void __launch_bounds__(kMaxWorkgroup) pmi_mix_kernel(const MixParams f)
 {
-    extern __shared__ float4 fin4[];
-    float4 *pose = fin4;                                        // [E*N] (x, y, z, raw)
+    extern __shared__ uint32_t mix_lds[];
     const int tid = threadIdx.x;
     const int N = f.N;
+    const int W = SMALL ? 2 : nbrec_mask_words(N), RS = W + 2;
     const int env0 = blockIdx.x * f.E;
     const int envs_here = min(f.E, f.SB - env0);
     const int e = tid / N, i = tid - e * N;
     const bool active = tid < f.E * N && e < envs_here;
     const size_t gid = (size_t)(env0 + e) * N + i;
     if (blockIdx.x == 0 && tid == 0) *f.pair_count = 0;
-    float4 me = make_float4(0, 0, 0, 0);
     if (active) {
-        me = f.pose[gid];
-        pose[tid] = me;
+        if (SMALL) reinterpret_cast<uint4 *>(mix_lds)[tid] = reinterpret_cast<const uint4 *>(f.nbrec)[gid];
+        else
+            for (int w = 0; w < RS; ++w) mix_lds[(size_t)tid * RS + w] = f.nbrec[gid * RS + w];
     }
     __syncthreads();
     if (!active) return;
-    const float x = me.x, y = me.y, z = me.z, raw_i = me.w;
-    const float *srow = f.scores + gid * N;
-    const float4 *pe = pose + e * N;
-    // pass 1: max score over neighbours (dist2() of step_kernel.hip: the pair emission's expression)
-    float mx = -INFINITY;
-    int cnt = 0;
-    for (int j = 0; j < N; ++j) {
-        const float4 pj = pe[j];
-        const float sj = srow[j];
-        float d2 = fmaf(pj.y - y, pj.y - y, (pj.x - x) * (pj.x - x));
-        if (f.three_d) { const float dz = pj.z - z; d2 = fmaf(dz, dz, d2); }
-        const bool nb = j != i && d2 <= f.dp2;
-        mx = nb ? fmaxf(mx, sj) : mx;
-        cnt += nb ? 1 : 0;
-    }
+    const uint32_t *env_rec = mix_lds + (size_t)e * N * RS;
+    const uint32_t *me = env_rec + (size_t)i * RS;
+    const float raw_i = __uint_as_float(me[W + 1]);
     float r = (1.0f - f.coop) * raw_i;                                 // uav.py:290
-    if (cnt) {
-        float den = 0.0f, num = 0.0f;
-        for (int j = 0; j < N; ++j) {
-            const float4 pj = pe[j];
-            const float sj = srow[j];
-            float d2 = fmaf(pj.y - y, pj.y - y, (pj.x - x) * (pj.x - x));
-            if (f.three_d) { const float dz = pj.z - z; d2 = fmaf(dz, dz, d2); }
-            if (j != i && d2 <= f.dp2) {                             // scipy softmax, uav.py:287
-                const float ew = expf(sj - mx);
+    if (SMALL) {
+        const unsigned long long mask = (unsigned long long)me[0] | ((unsigned long long)me[1] << 32);
+        if (mask) {
+            auto slot_of = [&](int j) {                // where s_ij lives: emitted by the lower index
+                const int lo = j > i ? i : j, hi = j > i ? j : i;
+                const uint32_t *rl = env_rec + (size_t)lo * RS;
+                const unsigned long long ml = (unsigned long long)rl[0] | ((unsigned long long)rl[1] << 32);
+                const unsigned long long later = (lo + 1 < 64) ? (ml >> (lo + 1)) << (lo + 1) : 0ull;
+                return rl[2] + (unsigned)__popcll(later & ((1ull << hi) - 1ull));
+            };
+            float mx = -INFINITY;
+            for (unsigned long long m = mask; m; m &= m - 1) mx = fmaxf(mx, f.scores[slot_of(__ffsll((long long)m) - 1)]);
+            float den = 0.0f, num = 0.0f;
+            for (unsigned long long m = mask; m; m &= m - 1) {          // ascending j: scipy softmax, uav.py:287
+                const int j = __ffsll((long long)m) - 1;
+                const float ew = expf(f.scores[slot_of(j)] - mx);
                 den += ew;
-                num = fmaf(ew, pj.w, num);
+                num = fmaf(ew, __uint_as_float(env_rec[(size_t)j * RS + 3]), num);
             }
+            r = fmaf(f.coop, num / den, r);                              // uav.py:288
         }
-        r = fmaf(f.coop, num / den, r);                              // uav.py:288
+    } else {
+        auto bit = [&](const uint32_t *rec, int j) { return (rec[j >> 5] >> (j & 31)) & 1u; };
+        auto slot_of = [&](int j) {
+            const int lo = j > i ? i : j, hi = j > i ? j : i;
+            const uint32_t *rl = env_rec + (size_t)lo * RS;
+            unsigned rank = 0;
+            for (int k = lo + 1; k < hi; ++k) rank += bit(rl, k);
+            return rl[W] + rank;
+        };
+        float mx = -INFINITY;
+        int cnt = 0;
+        for (int j = 0; j < N; ++j)
+            if (bit(me, j)) { mx = fmaxf(mx, f.scores[slot_of(j)]); ++cnt; }
+        if (cnt) {
+            float den = 0.0f, num = 0.0f;
+            for (int j = 0; j < N; ++j)
+                if (bit(me, j)) {
+                    const float ew = expf(f.scores[slot_of(j)] - mx);
+                    den += ew;
+                    num = fmaf(ew, __uint_as_float(env_rec[(size_t)j * RS + W + 1]), num);
+                }
+            r = fmaf(f.coop, num / den, r);
+        }
     }
     f.reward[gid] = fminf(fmaxf(r, -1.0f), 1.0f);                    // environment.py:225
 }
@@ -360,16 +410,19 @@ hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream
 hipError_t launch_pmi_finalize(const uavtrack_env *env, int steps, float *reward, hipStream_t stream)
 {
     const uavtrack_config &c = env->cfg;
-    FinalizeParams f;
-    f.pose = env->pose; f.scores = env->scores; f.reward = reward;
+    MixParams f;
+    f.nbrec = env->nbrec; f.scores = env->scores; f.reward = reward;
     f.pair_count = env->pair_count;
-    // one lane per UAV-step (the rollout kernel's lanes hold UAV pairs: this kernel has its own geometry)
+    // one lane per UAV-step (the rollout kernel's geometry is its own)
     const int wgs = c.n_uav <= 256 ? 256 : kMaxWorkgroup;
-    f.SB = steps * c.n_envs; f.N = c.n_uav; f.E = wgs / c.n_uav; f.three_d = c.dim == 3;
-    f.dp2 = env->base.dp2; f.coop = env->base.coop;
+    f.SB = steps * c.n_envs; f.N = c.n_uav; f.E = wgs / c.n_uav;
+    f.coop = env->base.coop;
     const unsigned groups = (unsigned)((f.SB + f.E - 1) / f.E);
-    const size_t lds = (size_t)f.E * f.N * 16;
-    hipLaunchKernelGGL(pmi_finalize_kernel, dim3(groups), dim3(wgs), lds, stream, f);
+    const size_t lds = (size_t)f.E * f.N * nbrec_words(c.n_uav) * 4;
+    if (c.n_uav <= 64)
+        hipLaunchKernelGGL(pmi_mix_kernel<true>, dim3(groups), dim3(wgs), lds, stream, f);
+    else
+        hipLaunchKernelGGL(pmi_mix_kernel<false>, dim3(groups), dim3(wgs), lds, stream, f);
     return hipGetLastError();
 }
 

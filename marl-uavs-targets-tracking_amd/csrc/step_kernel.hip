@@ -396,7 +396,6 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     constexpr bool GIVEN = POLICY == kPolicyGiven;
     extern __shared__ float4 smem4[];
     if (ALLOUT) __builtin_assume(p.obs != nullptr && p.reward != nullptr && p.terms != nullptr && p.covered != nullptr && p.done != nullptr);
-    if (MODE != UAVTRACK_REWARD_PMI) __builtin_assume(p.pose_out == nullptr);      // the MAAC-R chunk driver alone passes it
     if (POLICY == kPolicyGiven) __builtin_assume(p.actions != nullptr);
     const int N = N_ > 0 ? N_ : p.N;
     const int M = M_ > 0 ? M_ : p.M;
@@ -789,7 +788,6 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                 op[2] = make_float4(o[8], o[9], o[10], o[11]);
             }
             if (p.reward) *at(p.reward + row, g32 * 4u) = r;
-            if (p.pose_out) *at(p.pose_out + row, g32 * 16u) = make_float4(x, y, z, raw);
             if (p.terms) {                                    // [t][3][b][i]
                 float *tp = p.terms + 3 * row;
                 *at(tp, g32 * 4u) = tt;
@@ -806,39 +804,59 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             unsigned *wg_cnt = covw + 2 * E * CW;          // two extra words behind the coverage masks
             if (tid == 0) wg_cnt[0] = 0;
             __syncthreads();
+            // One record per agent-step for the mix kernel (internal.h, nbrec_words): the neighbour mask, where this
+            // UAV's pairs start in the pair list (their scores land in the same slots), and the raw reward.
+            const int W = nbrec_mask_words(N);
             int mine = 0, slot = 0;
-            unsigned long long later = 0;                   // neighbours j > i
+            unsigned long long nball = 0, later = 0;        // all neighbours / neighbours j > i   (N <= 64)
+            auto is_neighbour = [&](int j) {
+                const UavRow nw = uav_elem(rowNew, j);
+                float d2 = dist2(nw.x - x, nw.y - y);
+                if (Z3) { const float dz = nw.z - z; d2 = fmaf(dz, dz, d2); }
+                return j != i && d2 <= p.dp2;
+            };
             if (active) {
                 if (kMask) {
-                    later = (i + 1 < 64) ? (nbmask >> (i + 1)) << (i + 1) : 0ull;
+                    nball = nbmask & ~(1ull << i);
+                } else if (N <= 64) {
+                    for (int j = 0; j < N; ++j) nball |= (unsigned long long)(is_neighbour(j) ? 1u : 0u) << j;
+                }
+                if (N <= 64) {
+                    later = (i + 1 < 64) ? (nball >> (i + 1)) << (i + 1) : 0ull;
                     mine = __popcll(later);
                 } else {
-                    for (int j = i + 1; j < N; ++j) {
-                        const UavRow nw = uav_elem(rowNew, j);
-                        float d2 = dist2(nw.x - x, nw.y - y);
-                        if (Z3) { const float dz = nw.z - z; d2 = fmaf(dz, dz, d2); }
-                        mine += (d2 <= p.dp2) ? 1 : 0;
-                    }
+                    for (int j = i + 1; j < N; ++j) mine += is_neighbour(j) ? 1 : 0;
                 }
                 if (mine) slot = (int)atomicAdd(&wg_cnt[0], (unsigned)mine);
             }
             __syncthreads();
             if (tid == 0) wg_cnt[1] = wg_cnt[0] ? atomicAdd(p.pair_count, wg_cnt[0]) : 0u;
             __syncthreads();
-            if (active && mine) {
-                uint2 *dst = p.pairs + wg_cnt[1] + slot;
-                if (kMask) {
-                    while (later) {                          // ascending j
-                        const int j = __ffsll((long long)later) - 1;
-                        later &= later - 1;
-                        *dst++ = make_uint2((unsigned)tg_off, (unsigned)j);
-                    }
+            if (active) {
+                const unsigned first = wg_cnt[1] + (unsigned)slot;
+                uint32_t *rec = p.nbrec + (size_t)tg_off * (W + 2);
+                if (N <= 64) {
+                    *reinterpret_cast<uint4 *>(rec) = make_uint4((unsigned)nball, (unsigned)(nball >> 32), first, __float_as_uint(raw));
                 } else {
-                    for (int j = i + 1; j < N; ++j) {
-                        const UavRow nw = uav_elem(rowNew, j);
-                        float d2 = dist2(nw.x - x, nw.y - y);
-                        if (Z3) { const float dz = nw.z - z; d2 = fmaf(dz, dz, d2); }
-                        if (d2 <= p.dp2) *dst++ = make_uint2((unsigned)tg_off, (unsigned)j);
+                    for (int w = 0; w < W; ++w) {
+                        unsigned bits = 0;
+                        for (int j = 32 * w; j < min(N, 32 * w + 32); ++j) bits |= (is_neighbour(j) ? 1u : 0u) << (j - 32 * w);
+                        rec[w] = bits;
+                    }
+                    rec[W] = first;
+                    rec[W + 1] = __float_as_uint(raw);
+                }
+                if (mine) {
+                    uint2 *dst = p.pairs + first;
+                    if (N <= 64) {
+                        while (later) {                      // ascending j
+                            const int j = __ffsll((long long)later) - 1;
+                            later &= later - 1;
+                            *dst++ = make_uint2(tg_off, (unsigned)j);
+                        }
+                    } else {
+                        for (int j = i + 1; j < N; ++j)
+                            if (is_neighbour(j)) *dst++ = make_uint2(tg_off, (unsigned)j);
                     }
                 }
             }
