@@ -146,6 +146,18 @@ int uavtrack_step_many(uavtrack_env *env, int32_t T, const int32_t *actions,
                        float *obs, float *reward, float *terms,
                        int32_t *covered, uint8_t *done, float *ep_sums, void *stream);
 
+/* uavtrack_step_many with automatic episode turnover (rollouts of T steps "with auto-reset at done"): an
+ * environment whose done flag fires at step t (step_count reached cfg.horizon) is reset right behind that step, inside
+ * the launch -- exactly uavtrack_reset(reset_seed, e + 1) for that environment, e being the episode number of its
+ * previous reset (uavtrack_reset stores its `episode` argument per environment) -- so one launch may span episodes
+ * and the driver's per-episode reset launch disappears.  Row t of the outputs is the terminal step, as without the
+ * reset; row t + 1 is the first step of the new episode (the reset state's own observation, [-1]*9 + [x/dc, y/dc, a/Na],
+ * is not emitted; an in-kernel policy sees it).  Bitwise identical to: uavtrack_step_many up to each done step,
+ * uavtrack_reset, continue.  ep_sums runs over the whole call.  Needs cfg.horizon >= 1. */
+int uavtrack_step_many_autoreset(uavtrack_env *env, int32_t T, uint64_t reset_seed, const int32_t *actions,
+                                 float *obs, float *reward, float *terms,
+                                 int32_t *covered, uint8_t *done, float *ep_sums, void *stream);
+
 /* uavtrack_step that also ADDS this step's contribution to the caller's running episode
  * accumulators ep_sums [B][5] (same five sums as uavtrack_step_many, train.py:181-192), so a
  * closed-loop driver needs no reduction kernels of its own.  ep_sums must not be NULL. */
@@ -204,6 +216,15 @@ int uavtrack_actor_actions(uavtrack_env *env, const float *obs, uint64_t seed, i
 int uavtrack_run_actor(uavtrack_env *env, int32_t T, uint64_t seed, int32_t mode, const float *obs_in,
                        int32_t *actions_out, float *obs, float *reward, float *terms,
                        int32_t *covered, uint8_t *done, float *ep_sums, void *stream);
+
+/* Optional extra output of every stepping entry point (uavtrack_step, _step_accumulate, _step_many, _run_greedy,
+ * _run_actor): the target positions after each step, tpos [T][B][M][2] = (x, y) -- what Environment.step appends to
+ * position['all_target_xs'/'all_target_ys'] (environment.py:150-153) and Environment.save_position writes to
+ * t_xy<ep>.csv (environment.py:232-238).  (UAV positions are already in the observations: obs[..., 9:11] * dc,
+ * uav.py:154.)  The buffer, a device pointer like the others, is written by every later stepping call -- row t of the
+ * call's T steps at tpos[t] -- until it is replaced; it must hold capacity_steps >= the largest T passed while it
+ * is set (checked).  tpos = NULL switches the output off (the default). */
+int uavtrack_set_target_trace(uavtrack_env *env, float *tpos, int32_t capacity_steps);
 
 /* MAAC-R accounting for reports: out[0] = neighbour pairs scored by the PMI network since
  * the weights were set (each unordered pair once per step).  Synchronises `stream`. */

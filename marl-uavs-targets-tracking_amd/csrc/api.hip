@@ -149,6 +149,7 @@ void fold_constants(const uavtrack_config &c, StepParams &p, float *climb_c, flo
     p.B = c.n_envs; p.N = c.n_uav; p.M = c.m_targets;
     p.na = c.na; p.na_total = c.na * c.nc; p.horizon = c.horizon;
     p.x_max = (float)c.x_max; p.y_max = (float)c.y_max; p.z_max = (float)c.z_max;
+    p.x_max_d = c.x_max; p.y_max_d = c.y_max; p.z_max_d = c.z_max;
     p.dtv_u = (float)(c.dt * c.u_v_max);
     p.dtv_t = (float)(c.dt * c.t_v_max);
     p.turn_unit = (float)(c.dt * c.u_h_max / (double)(c.na - 1));
@@ -347,33 +348,56 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
         env->pmi = PmiWeights();
         return 0;
     }
-    if (!pmi_hidden_supported(hidden))
-        return fail("uavtrack_set_pmi_weights: hidden %d not built; this build has the MFMA scorer for 64 and 128 "
-                    "(configs/MAAC-R.yaml uses 128, PMINetwork's default is 64)", hidden);
+    if (hidden < 1 || hidden > kPmiMaxHidden)
+        return fail("uavtrack_set_pmi_weights: hidden %d outside [1, %d] (PMINetwork takes any hidden_dim, PMINet.py:19; the "
+                    "MFMA scorer is built for widths up to %d)", hidden, kPmiMaxHidden, kPmiMaxHidden);
     const size_t H = (size_t)hidden;
     const size_t want = 12 * H + 3 * H + 3 * H * H + H + H + 1;
     if (n_floats != want)
         return fail("uavtrack_set_pmi_weights: n_floats %zu != %zu for hidden %d", n_floats, want, hidden);
-    if (env->pmi.n_floats != n_floats) {
+    // The scorer tiles the hidden layer in blocks of 32 columns: other widths are padded with units whose weights
+    // and biases are zero (relu(0) = 0 adds nothing to any sum), so every hidden_dim runs on the same kernels.
+    const int hp = pmi_padded_hidden(hidden);
+    const size_t HP = (size_t)hp, n_dev = 12 * HP + 3 * HP + 3 * HP * HP + HP + HP + 1;
+    if (env->pmi.n_floats != n_dev) {
         HIP_TRY(hipStreamSynchronize(st));
         if (env->pmi.blob) (void)hipFree(env->pmi.blob);
         env->pmi = PmiWeights();
-        HIP_TRY(dmalloc(&env->pmi.blob, n_floats));
+        HIP_TRY(dmalloc(&env->pmi.blob, n_dev));
     }
     {   // fc1 goes up in the scorer's register order; the copy has completed before `packed` dies
-        std::vector<float> packed(n_floats);
-        pack_pmi_blob(folded, packed.data(), hidden);
-        HIP_TRY(hipMemcpyAsync(env->pmi.blob, packed.data(), n_floats * 4, hipMemcpyHostToDevice, st));
+        std::vector<float> padded(n_dev, 0.0f), packed(n_dev);
+        const float *src = folded;
+        float *dst = padded.data();
+        auto rows = [&](size_t nrows, size_t in_w, size_t out_w) {      // nrows rows of in_w floats -> rows of out_w
+            for (size_t r = 0; r < nrows; ++r) memcpy(dst + r * out_w, src + r * in_w, in_w * sizeof(float));
+            src += nrows * in_w;
+            dst += nrows * out_w;
+        };
+        rows(5 + 1, H, HP);                       // Wc[5][H] bc[H]
+        rows(4 + 1, H, HP);                       // Wo[4][H] bo[H]
+        rows(3 + 1, H, HP);                       // Wb[3][H] bb[H]
+        for (int br = 0; br < 3; ++br) {          // W1[3H][H]: the three branch blocks of its input, each padded to HP rows
+            rows(H, H, HP);
+            dst += (HP - H) * HP;
+        }
+        rows(1, H, HP);                           // b1[H]
+        rows(1, H, HP);                           // w2[H]
+        rows(1, 1, 1);                            // b2
+        pack_pmi_blob(padded.data(), packed.data(), hp);
+        HIP_TRY(hipMemcpyAsync(env->pmi.blob, packed.data(), n_dev * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
-    env->pmi.hidden = hidden;
-    env->pmi.n_floats = n_floats;
+    env->pmi.hidden = hp;
+    env->pmi.n_floats = n_dev;
     if (ensure_pmi_scratch(env, 1, st)) return 1;
     return 0;
 }
 
 // Where a rollout's actions come from: the caller's tensor, or the in-kernel actor (uavtrack_run_actor).
 struct PolicyArgs {
+    bool auto_reset = false;           // uavtrack_step_many_autoreset: reset seed
+    uint64_t reset_seed = 0;
     int policy = kPolicyGiven;
     const float *obs_in = nullptr;     // actor: observation seen at the first step
     int32_t *actions_out = nullptr;    // actor: chosen actions [T][B][N], nullable
@@ -391,14 +415,19 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
     if (!reward) return fail("%s: reward is null", who);
     ON_DEVICE(env->cfg.device_id);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (env->tpos && T > env->tpos_steps)
+        return fail("%s: T = %d exceeds the %d steps the target-trace buffer holds (uavtrack_set_target_trace)", who, T, env->tpos_steps);
     StepParams p = env->base;
     p.actions = actions;
+    p.tpos = env->tpos;
     p.obs = obs; p.reward = reward; p.terms = terms; p.nbrec = nullptr;
     p.covered = covered; p.done = done; p.ep_sums = ep_sums;
     p.pairs = nullptr; p.pair_count = nullptr;
     p.ep_accumulate = accumulate ? 1 : 0;
     p.actions_out = pol.actions_out;
     p.env_offset = env->cfg.env_offset;
+    p.auto_reset = pol.auto_reset ? 1 : 0;
+    p.reset_k0 = (uint32_t)pol.reset_seed; p.reset_k1 = (uint32_t)(pol.reset_seed >> 32);
     if (pol.policy == kPolicyActor) {
         p.greedy_k0 = (uint32_t)pol.seed; p.greedy_k1 = (uint32_t)(pol.seed >> 32);
         p.obs_in = pol.obs_in; p.actor_w = env->actor_w; p.actor_hblocks = actor_blocks(env->actor_hidden);
@@ -435,6 +464,7 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
         p.obs = obs_t; p.reward = reward_t; p.terms = terms_t;
         p.covered = covered_t;
         p.done = done ? done + (size_t)t0 * c.n_envs : nullptr;
+        p.tpos = env->tpos ? env->tpos + (size_t)t0 * c.n_envs * c.m_targets : nullptr;
         HIP_TRY(launch_rollout(env, p, st, pol.policy));
         // the actor of the next chunk starts from this chunk's last observation (a lane reads its own row
         // once, at launch start, before it writes anything: the scratch buffer may be reused in place)
@@ -469,6 +499,15 @@ int uavtrack_step_many(uavtrack_env *env, int32_t T, const int32_t *actions, flo
     return run_steps(env, T, actions, obs, reward, terms, covered, done, ep_sums, stream, "uavtrack_step_many");
 }
 
+int uavtrack_step_many_autoreset(uavtrack_env *env, int32_t T, uint64_t reset_seed, const int32_t *actions, float *obs,
+                                 float *reward, float *terms, int32_t *covered, uint8_t *done, float *ep_sums, void *stream)
+{
+    if (env && env->cfg.horizon < 1) return fail("uavtrack_step_many_autoreset: the configuration has no horizon (done never fires)");
+    PolicyArgs pol;
+    pol.auto_reset = true; pol.reset_seed = reset_seed;
+    return run_steps(env, T, actions, obs, reward, terms, covered, done, ep_sums, stream, "uavtrack_step_many_autoreset", false, pol);
+}
+
 int uavtrack_run_greedy(uavtrack_env *env, int32_t T, uint64_t seed, int32_t *actions_out, float *obs, float *reward,
                         float *terms, int32_t *covered, uint8_t *done, float *ep_sums, void *stream)
 {
@@ -479,8 +518,11 @@ int uavtrack_run_greedy(uavtrack_env *env, int32_t T, uint64_t seed, int32_t *ac
     if (env->cfg.reward_mode == UAVTRACK_REWARD_PMI)
         return fail("uavtrack_run_greedy: the C-METHOD baseline runs with the MAAC / MAAC-G rewards (C-METHOD.yaml: cooperative 0)");
     ON_DEVICE(env->cfg.device_id);
+    if (env->tpos && T > env->tpos_steps)
+        return fail("uavtrack_run_greedy: T = %d exceeds the %d steps the target-trace buffer holds", T, env->tpos_steps);
     StepParams p = env->base;
     p.T = T;
+    p.tpos = env->tpos;
     p.actions = nullptr; p.actions_out = actions_out;
     p.obs = obs; p.reward = reward; p.terms = terms; p.nbrec = nullptr;
     p.covered = covered; p.done = done; p.ep_sums = ep_sums;
@@ -568,6 +610,15 @@ int uavtrack_run_actor(uavtrack_env *env, int32_t T, uint64_t seed, int32_t mode
     PolicyArgs pol;
     pol.policy = kPolicyActor; pol.obs_in = obs_in; pol.actions_out = actions_out; pol.seed = seed; pol.mode = mode;
     return run_steps(env, T, nullptr, obs, reward, terms, covered, done, ep_sums, stream, "uavtrack_run_actor", false, pol);
+}
+
+int uavtrack_set_target_trace(uavtrack_env *env, float *tpos, int32_t capacity_steps)
+{
+    if (!env) return fail("uavtrack_set_target_trace: null handle");
+    if (tpos && capacity_steps < 1) return fail("uavtrack_set_target_trace: capacity_steps must be >= 1 (got %d)", capacity_steps);
+    env->tpos = reinterpret_cast<float2 *>(tpos);
+    env->tpos_steps = tpos ? capacity_steps : 0;
+    return 0;
 }
 
 int uavtrack_pmi_pairs_scored(uavtrack_env *env, uint64_t *out, void *stream)

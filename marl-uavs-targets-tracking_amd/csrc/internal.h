@@ -18,13 +18,14 @@ constexpr int kMaxWorkgroup = 512;   // __launch_bounds__ of the rollout kernel
 // The state arrays live in ONE device slab at offsets that follow from (B, N, M, dim), so the kernel
 // carries a single base pointer (2 SGPRs instead of 20 through the whole step loop) and derives the
 // rest with scalar adds -- no dependent pointer load at the start of a launch.  Slab order (4-byte
-// units): ux uy uh ua [uz] (B*N each), tx ty th [tz] (B*M each), step_count (B), climb_c climb_s (8 each).
+// units): ux uy uh ua [uz] (B*N each), tx ty th [tz] (B*M each), step_count (B), episode (B), climb_c climb_s (8 each).
 struct StateBlock {
     // state, SoA over (env, uav) and (env, target); updated in place
     float *ux, *uy, *uz, *uh;
     int32_t *ua;
     float *tx, *ty, *tz, *th;
     int32_t *step_count;
+    int32_t *episode;           // episode number of each environment's last reset (keys the next automatic one)
     float *climb_c, *climb_s;   // cos/sin of the climb angles (UAVTRACK_MAX_CLIMB each)
 };
 
@@ -43,13 +44,14 @@ __host__ __device__ inline StateBlock state_view(float *slab, int B, int N, int 
     v.th = f; f += BM;
     v.tz = z3 ? f : nullptr; if (z3) f += BM;
     v.step_count = reinterpret_cast<int32_t *>(f); f += B;
+    v.episode = reinterpret_cast<int32_t *>(f); f += B;
     v.climb_c = f; f += UAVTRACK_MAX_CLIMB;
     v.climb_s = f;
     return v;
 }
 inline size_t state_slab_floats(int B, int N, int M, bool z3)
 {
-    return ((size_t)B * N) * (z3 ? 5 : 4) + ((size_t)B * M) * (z3 ? 4 : 3) + (size_t)B + 2 * UAVTRACK_MAX_CLIMB;
+    return ((size_t)B * N) * (z3 ? 5 : 4) + ((size_t)B * M) * (z3 ? 4 : 3) + 2 * (size_t)B + 2 * UAVTRACK_MAX_CLIMB;
 }
 
 struct StepParams {
@@ -57,6 +59,7 @@ struct StepParams {
     // per-step I/O, leading [T] axis
     const int32_t *actions;
     float *obs, *reward, *terms;
+    float2 *tpos;            // optional target trace [T][B][M] (x, y) after each step (uavtrack_set_target_trace)
     uint32_t *nbrec;         // MAAC-R: neighbour record per agent-step, read by the deferred softmax mix (nbrec_words())
     int32_t *covered;
     uint8_t *done;
@@ -66,6 +69,10 @@ struct StepParams {
     // geometry
     int32_t B, N, M, E, T, na, na_total, horizon;
     int32_t ep_accumulate;   // 1: ep_sums += (uavtrack_step_accumulate), 0: ep_sums = sums of this launch
+    // automatic episode turnover (uavtrack_step_many_autoreset): an environment whose done flag fires is reset in place
+    int32_t auto_reset;
+    uint32_t reset_k0, reset_k1;     // reset seed (Philox key), as uavtrack_reset
+    double x_max_d, y_max_d, z_max_d;
     // fused greedy rollout (uavtrack_run_greedy): actions come from the in-kernel baseline policy
     int32_t *actions_out;    // [T][B][N], nullable
     int64_t env_offset;
@@ -132,6 +139,8 @@ struct uavtrack_env {
     unsigned long long *pair_total = nullptr;
     float *scores = nullptr, *obs_tmp = nullptr, *terms_tmp = nullptr;   // scores: one per emitted pair
     uint32_t *nbrec = nullptr;
+    float2 *tpos = nullptr;           // caller's target-trace buffer (not owned), capacity in steps
+    int32_t tpos_steps = 0;
     int32_t *covered_tmp = nullptr;   // [steps][B] coverage counts for ep_sums when the caller passes covered = NULL
 };
 
@@ -144,7 +153,8 @@ hipError_t launch_rollout(const uavtrack_env *env, const StepParams &p, hipStrea
 size_t rollout_lds_bytes(const uavtrack_env *env, int policy);   // dynamic LDS of a rollout launch with that policy
 
 // pmi_kernel.hip
-bool pmi_hidden_supported(int hidden);
+constexpr int kPmiMaxHidden = 256;                  // widest PMINetwork hidden layer the scorer is instantiated for
+inline int pmi_padded_hidden(int hidden) { return (hidden + 31) / 32 * 32; }   // the scorer's column-block granule
 void pack_pmi_blob(const float *abi_blob, float *device_order, int hidden);
 hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream_t stream);
 hipError_t launch_pmi_finalize(const uavtrack_env *env, int steps, float *reward, hipStream_t stream);

@@ -363,8 +363,6 @@ __global__ void __launch_bounds__(kMaxWorkgroup) ep_sums_kernel(const EpParams q
 
 }  // namespace
 
-bool pmi_hidden_supported(int hidden) { return hidden == 64 || hidden == 128; }
-
 // Host-side repack of the fc1 block of the ABI blob (W1[3H][H], input-major) into the order the
 // scorer's lanes load it: [column block w][k-step group t4][lane][4], element q of lane l being
 // W1[2 (4 t4 + q) + (l >> 5)][32 w + (l & 31)].
@@ -397,13 +395,17 @@ hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream
     // persistent workgroups grid-striding over 32-pair tiles, two per CU: __launch_bounds__(2H, 2) holds
     // the kernel to 256 registers per lane (a few spills at H = 128) so that one workgroup's branch
     // layers / epilogue overlap the other's MFMAs -- measured +12 % over one 296-register workgroup
+    // Built for every multiple of 32 up to kPmiMaxHidden (uavtrack_set_pmi_weights pads other widths); tuned at the
+    // reference's two: 128 (configs/MAAC-R.yaml) and 64 (the class default).  Past 128 the stationary slice no longer
+    // fits 256 registers and part of it lives in scratch: correct, slower.
     const int grid = 512;
-    if (env->pmi.hidden == 128)
-        hipLaunchKernelGGL(pmi_score_kernel<128>, dim3(grid), dim3(256), 0, stream, q);
-    else if (env->pmi.hidden == 64)
-        hipLaunchKernelGGL(pmi_score_kernel<64>, dim3(grid), dim3(128), 0, stream, q);
-    else
-        return hipErrorInvalidValue;
+    switch (env->pmi.hidden) {
+#define UAVTRACK_PMI_CASE(HH) case HH: hipLaunchKernelGGL(pmi_score_kernel<HH>, dim3(grid), dim3(2 * HH), 0, stream, q); break;
+        UAVTRACK_PMI_CASE(32) UAVTRACK_PMI_CASE(64) UAVTRACK_PMI_CASE(96) UAVTRACK_PMI_CASE(128)
+        UAVTRACK_PMI_CASE(160) UAVTRACK_PMI_CASE(192) UAVTRACK_PMI_CASE(224) UAVTRACK_PMI_CASE(256)
+#undef UAVTRACK_PMI_CASE
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -16,7 +16,7 @@ struct ResetParams {
     float *ux, *uy, *uz, *uh;
     int32_t *ua;
     float *tx, *ty, *tz, *th;
-    int32_t *step_count;
+    int32_t *step_count, *episode_out;
     float *obs;
     int32_t B, N, M, dim, na_total;
     int64_t env_offset;
@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(256) reset_kernel(const ResetParams p)
         const int a = (int)(((uint64_t)r.v[1] * (uint32_t)p.na_total) >> 32);
         p.ux[g] = x; p.uy[g] = y; p.uh[g] = h; p.ua[g] = a;
         if (p.dim == 3) p.uz[g] = (float)(p.z_max / 2.0);
-        if (idx == 0) p.step_count[b] = 0;
+        if (idx == 0) { p.step_count[b] = 0; p.episode_out[b] = (int32_t)p.episode; }
         if (p.obs) {   // get_states() with empty observation lists (uav.py:174,186)
             float4 *o = reinterpret_cast<float4 *>(p.obs + g * UAVTRACK_OBS_DIM);
             o[0] = make_float4(-1.f, -1.f, -1.f, -1.f);
@@ -71,7 +71,7 @@ hipError_t launch_reset(const uavtrack_env *env, uint64_t seed, uint32_t episode
     ResetParams p;
     p.ux = s.ux; p.uy = s.uy; p.uz = s.uz; p.uh = s.uh; p.ua = s.ua;
     p.tx = s.tx; p.ty = s.ty; p.tz = s.tz; p.th = s.th;
-    p.step_count = s.step_count;
+    p.step_count = s.step_count; p.episode_out = s.episode;
     p.obs = obs;
     p.B = c.n_envs; p.N = c.n_uav; p.M = c.m_targets; p.dim = c.dim;
     p.na_total = k.na_total;

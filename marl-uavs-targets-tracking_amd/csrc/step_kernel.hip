@@ -36,6 +36,7 @@
 
 #include "actor.h"
 #include "greedy.h"
+#include "philox.h"
 
 #include <cstdlib>
 
@@ -388,7 +389,9 @@ __device__ __forceinline__ void sweep_weighted(const StepParams &p, int N, int M
 
 // ALLOUT: the caller passed every per-step output (obs, reward, terms, covered, done) -- the rollout a learner
 // consumes and the benchmark workload; the nullable-pointer tests and their SGPR flags then fold away.
-template <int N_, int M_, int MODE, bool Z3, int POLICY, bool ALLOUT = false>
+// EXTRAS: the launch uses the rarely wanted per-step extras (target trace, automatic reset); compiled out otherwise --
+// their tests and parameters cost the plain rollout ~10 % when they sat in the same instantiation.
+template <int N_, int M_, int MODE, bool Z3, int POLICY, bool ALLOUT = false, bool EXTRAS = false>
 __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams p)
 {
     constexpr bool GREEDY = POLICY == kPolicyGreedy;
@@ -415,7 +418,8 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     float *rawl = fb;  fb += E * (N + 1);        // [E][N + 1]  raw reward (cooperative modes), pair-padded
     float *tzf = fb;   if (Z3) fb += E * MP * 2; // [E][pairs] (z0, z1)
     int *ncnt = reinterpret_cast<int *>(fb);  fb += E * M;   // [E][M] UAVs within dc of a target (greedy policy)
-    unsigned *covw = reinterpret_cast<unsigned *>(fb);   // [2][E * CW] (+ 2 words, MAAC-R pair emission)
+    unsigned *covw = reinterpret_cast<unsigned *>(fb);   // [2][E * CW] (+ 2 words, MAAC-R pair emission; + E words, automatic reset)
+    unsigned *rstw = covw + 2 * E * CW + 2;              // [E] 0, or 1 + the episode number an environment is being reset to
 
     const int grp = xcd_group(blockIdx.x, gridDim.x);
     const int env0 = grp * E;
@@ -435,6 +439,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     int ecov = 0;
     int pn = 0;                                   // which table copy is "post-move" this step
     unsigned cov_pending = 0;                     // coverage word of the previous step (deferred read-back)
+    int epi = 0;                                  // episode number of this environment's last reset
 
     // ---- load state once
     const StateBlock S = state_view(p.slab, p.B, N, M, Z3);
@@ -443,6 +448,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         if (Z3) z = S.uz[g];
         sincos_any(h, &s, &c);
         count = S.step_count[b];
+        if (EXTRAS) epi = S.episode[b];
         uav_store(uenv + 3, i, x, y, c, s, (float)a_prev, z);            // "previous" copy (1) for step 0
         if ((N & 1) && i == N - 1) {                                      // padding agent of the last pair
             uav_store(uenv, N, kFar, kFar, 0.f, 0.f, 0.f, 0.f);
@@ -589,11 +595,14 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                     tgt[4] = ttc; tgt[6] = tts;
                     tth = th;
                 }
+                if (EXTRAS && p.tpos) p.tpos[(rowb + env0) * M + tid] = make_float2(ttx, tty);   // optional trace, environment.py:150-153
             }
         } else {
             for (int q = tid; q < envs_here * M; q += nthreads) {
                 const int te = q / M, k = q - te * M;
-                advance_target(reinterpret_cast<float *>(ttab + te * tstride + (k >> 1) * 2) + (k & 1), q);
+                float *f = reinterpret_cast<float *>(ttab + te * tstride + (k >> 1) * 2) + (k & 1);
+                advance_target(f, q);
+                if (EXTRAS && p.tpos) p.tpos[(rowb + env0) * M + q] = make_float2(f[0], f[2]);
             }
         }
 
@@ -861,6 +870,55 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                 }
             }
         }
+        // ---- automatic episode turnover (uavtrack_step_many_autoreset): an environment whose done flag fired this step
+        //      becomes uavtrack_reset(seed, episode + 1) -- reset_kernel.hip's formulas -- before the next one.  The barrier
+        //      also keeps the table writes behind every read of this step.
+        if (EXTRAS && p.auto_reset) {
+            const bool fire = active && p.horizon > 0 && count >= p.horizon;
+            if (active && i == 0) rstw[e] = fire ? (unsigned)(epi + 1) + 1u : 0u;
+            if (__syncthreads_or(fire ? 1 : 0)) {
+                if (fire) {
+                    ++epi;
+                    const uint64_t genv = (uint64_t)(p.env_offset + b);
+                    const Philox4 r = philox4x32_10((uint32_t)genv, (uint32_t)epi, (uint32_t)i, 0x55415631u ^ (uint32_t)(genv >> 32),
+                                                    p.reset_k0, p.reset_k1);
+                    x = (float)((double)(i + 1) * p.x_max_d / (double)(N + 1));      // environment.py:105
+                    y = (float)(p.y_max_d / 2.0);                                    // environment.py:107
+                    if (Z3) z = (float)(p.z_max_d / 2.0);
+                    h = fmaf(u01(r.v[0]), kTwoPi, -kPi);
+                    a_prev = (int)(((uint64_t)r.v[1] * (uint32_t)p.na_total) >> 32);
+                    sincos_any(h, &s, &c);
+                    count = 0;
+                    uav_store(uenv + pn * 3, i, x, y, c, s, (float)a_prev, z);       // this step's copy: the next step's "previous" one
+                    o[0] = o[1] = o[2] = o[3] = o[4] = o[5] = o[6] = o[7] = o[8] = -1.0f;   // get_states() of a fresh state (uav.py:174,186)
+                    o[9] = x * p.inv_dc; o[10] = y * p.inv_dc; o[11] = (float)a_prev * p.inv_na_total;
+                }
+                auto reset_target = [&](int q, float &tx, float &ty, float &th, float &tc, float &ts) {
+                    const int te = q / M, k = q - te * M;
+                    const unsigned ep1 = rstw[te];
+                    if (!ep1) return false;
+                    const uint64_t genv = (uint64_t)(p.env_offset + env0 + te);
+                    const Philox4 r = philox4x32_10((uint32_t)genv, ep1 - 1u, (uint32_t)(N + k), 0x55415631u ^ (uint32_t)(genv >> 32),
+                                                    p.reset_k0, p.reset_k1);
+                    tx = u01(r.v[0]) * p.x_max;
+                    ty = u01(r.v[1]) * p.y_max;
+                    th = fmaf(u01(r.v[2]), kTwoPi, -kPi);
+                    sincos_any(th, &ts, &tc);
+                    float *f = reinterpret_cast<float *>(ttab + te * tstride + (k >> 1) * 2) + (k & 1);
+                    f[0] = tx; f[2] = ty; f[4] = tc; f[6] = ts;
+                    if (Z3) tzf[te * MP * 2 + k] = u01(r.v[3]) * p.z_max;
+                    return true;
+                };
+                if (one_target_per_lane) {
+                    if (my_target) reset_target(tid, ttx, tty, tth, ttc, tts);
+                } else {
+                    for (int q = tid; q < envs_here * M; q += nthreads) {
+                        float tx, ty, th, tc, ts;
+                        if (reset_target(q, tx, ty, th, tc, ts)) thd[q] = th;
+                    }
+                }
+            }
+        }
         pn ^= 1;
         row += BN;
         rowb += (size_t)p.B;
@@ -875,8 +933,16 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     if (active) {
         S.ux[g] = x; S.uy[g] = y; S.uh[g] = h; S.ua[g] = a_prev;
         if (Z3) S.uz[g] = z;
-        if (i == 0) S.step_count[b] = count;
+        if (i == 0) {
+            S.step_count[b] = count;
+            if (EXTRAS) S.episode[b] = epi;
+        }
     }
+    if (EXTRAS && p.auto_reset && Z3)      // (target altitudes only ever change at a reset)
+        for (int q = tid; q < envs_here * M; q += nthreads) {
+            const int te = q / M, k = q - te * M;
+            S.tz[(size_t)env0 * M + q] = tzf[te * MP * 2 + k];
+        }
     if (one_target_per_lane) {
         if (my_target) {
             const size_t gt = (size_t)env0 * M + tid;
@@ -918,70 +984,53 @@ size_t lds_bytes_for(int E, int N, int M, bool z3)
 {
     const size_t CW = cov_words(M), MP = pairs_of(M);
     const size_t f4 = (size_t)E * ustride_of(N) + (size_t)E * tstride_of(M);
-    const size_t f = (size_t)E * M + (size_t)E * (N + 1) + (z3 ? (size_t)E * MP * 2 : 0) + (size_t)E * M + 2 * E * CW + 2;
+    const size_t f = (size_t)E * M + (size_t)E * (N + 1) + (z3 ? (size_t)E * MP * 2 : 0) + (size_t)E * M + 2 * E * CW + 2 + E;
     return (f4 * 16 + f * 4 + 15) & ~(size_t)15;   // ustride >= 3 N float4 per env, so ep_sums staging (E N float4) fits
 }
 
 using KernelFn = void (*)(const StepParams);
 
-template <int N_, int M_>
-KernelFn pick_mode(int mode, bool z3, int policy, bool allout)
+template <int N_, int M_, int POLICY, bool ALLOUT, bool EXTRAS>
+KernelFn pick_reward(int mode, bool z3)
 {
-    if (policy == kPolicyGiven && allout) {
-        if (z3) {
-            switch (mode) {
-            case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, true, kPolicyGiven, true>;
-            case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, UAVTRACK_REWARD_PMI, true, kPolicyGiven, true>;
-            default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, true, kPolicyGiven, true>;
-            }
-        }
+    constexpr bool PLANAR_ONLY = POLICY == kPolicyGreedy;      // the baseline policy is planar and runs with MAAC / MAAC-G
+    if (z3 && !PLANAR_ONLY) {
         switch (mode) {
-        case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, false, kPolicyGiven, true>;
-        case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, UAVTRACK_REWARD_PMI, false, kPolicyGiven, true>;
-        default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, false, kPolicyGiven, true>;
-        }
-    }
-    if (policy == kPolicyGreedy) {   // planar baseline policy; MAAC / MAAC-G rewards
-        return mode == UAVTRACK_REWARD_MEAN ? rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, false, kPolicyGreedy>
-                                            : rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, false, kPolicyGreedy>;
-    }
-    if (policy == kPolicyActor) {
-        if (z3) {                    // na*nc <= 48 (three action tiles)
-            switch (mode) {
-            case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, true, kPolicyActor>;
-            case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, UAVTRACK_REWARD_PMI, true, kPolicyActor>;
-            default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, true, kPolicyActor>;
-            }
-        }
-        switch (mode) {              // na <= 12 (one action tile)
-        case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, false, kPolicyActor>;
-        case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, UAVTRACK_REWARD_PMI, false, kPolicyActor>;
-        default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, false, kPolicyActor>;
-        }
-    }
-    if (z3) {
-        switch (mode) {
-        case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, true, kPolicyGiven>;
-        case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, UAVTRACK_REWARD_PMI, true, kPolicyGiven>;
-        default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, true, kPolicyGiven>;
+        case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, !PLANAR_ONLY, POLICY, ALLOUT, EXTRAS>;
+        case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, PLANAR_ONLY ? UAVTRACK_REWARD_RAW : UAVTRACK_REWARD_PMI, !PLANAR_ONLY, POLICY, ALLOUT, EXTRAS>;
+        default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, !PLANAR_ONLY, POLICY, ALLOUT, EXTRAS>;
         }
     }
     switch (mode) {
-    case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, false, kPolicyGiven>;
-    case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, UAVTRACK_REWARD_PMI, false, kPolicyGiven>;
-    default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, false, kPolicyGiven>;
+    case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, false, POLICY, ALLOUT, EXTRAS>;
+    case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, PLANAR_ONLY ? UAVTRACK_REWARD_RAW : UAVTRACK_REWARD_PMI, false, POLICY, ALLOUT, EXTRAS>;
+    default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, false, POLICY, ALLOUT, EXTRAS>;
     }
 }
 
-KernelFn pick_kernel(int N, int M, int mode, bool z3, int *specialised, int policy = kPolicyGiven, bool allout = false)
+// Instantiations: pre-sampled actions with every output and no extras (the learner's rollout, the benchmark);
+// any policy without extras; any policy with them.
+template <int N_, int M_>
+KernelFn pick_mode(int mode, bool z3, int policy, bool allout, bool extras)
+{
+    if (policy == kPolicyGreedy)
+        return extras ? pick_reward<N_, M_, kPolicyGreedy, false, true>(mode, z3) : pick_reward<N_, M_, kPolicyGreedy, false, false>(mode, z3);
+    if (policy == kPolicyActor)
+        return extras ? pick_reward<N_, M_, kPolicyActor, false, true>(mode, z3) : pick_reward<N_, M_, kPolicyActor, false, false>(mode, z3);
+    if (extras) return pick_reward<N_, M_, kPolicyGiven, false, true>(mode, z3);
+    return allout ? pick_reward<N_, M_, kPolicyGiven, true, false>(mode, z3) : pick_reward<N_, M_, kPolicyGiven, false, false>(mode, z3);
+}
+
+KernelFn pick_kernel(int N, int M, int mode, bool z3, int *specialised, int policy = kPolicyGiven, bool allout = false,
+                     bool extras = false)
 {
     *specialised = 1;
-    if (N == 20 && M == 10) return pick_mode<20, 10>(mode, z3, policy, allout);
-    if (N == 50 && M == 25) return pick_mode<50, 25>(mode, z3, policy, allout);
-    if (N == 10 && M == 10) return pick_mode<10, 10>(mode, z3, policy, allout);
-    if (N == 5 && M == 3) return pick_mode<5, 3>(mode, z3, policy, allout);
+    if (N == 20 && M == 10) return pick_mode<20, 10>(mode, z3, policy, allout, extras);
+    if (N == 50 && M == 25) return pick_mode<50, 25>(mode, z3, policy, allout, extras);
+    if (N == 10 && M == 10) return pick_mode<10, 10>(mode, z3, policy, allout, extras);
+    if (N == 5 && M == 3) return pick_mode<5, 3>(mode, z3, policy, allout, extras);
     *specialised = 0;
-    return pick_mode<0, 0>(mode, z3, policy, allout);
+    return pick_mode<0, 0>(mode, z3, policy, allout, extras);
 }
 
 }  // namespace
@@ -1056,7 +1105,8 @@ hipError_t launch_rollout(const uavtrack_env *env, const StepParams &p, hipStrea
 {
     int spec = 0;
     const bool allout = p.obs && p.reward && p.terms && p.covered && p.done;
-    KernelFn fn = pick_kernel(p.N, p.M, env->cfg.reward_mode, env->cfg.dim == 3, &spec, policy, allout);
+    const bool extras = p.auto_reset || p.tpos;
+    KernelFn fn = pick_kernel(p.N, p.M, env->cfg.reward_mode, env->cfg.dim == 3, &spec, policy, allout, extras);
     const Geometry &g = env->geo;
     StepParams q = p;
     if (policy == kPolicyActor) q.actor_lds_off = (int32_t)g.lds_bytes;

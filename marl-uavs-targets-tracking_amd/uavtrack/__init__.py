@@ -11,7 +11,8 @@ from .compat import Environment  # noqa: F401
 from .pmi import fold_pmi_state_dict, make_pmi_net  # noqa: F401
 from .sharding import shard_range, gather_rollout_summary, gather_rollout_summary_async  # noqa: F401
 from .rollout import ActorMLP, BatchedRollout, sample_actions  # noqa: F401
-from .export import uav_tracks_from_obs, save_uav_positions, save_covered_num  # noqa: F401
+from .export import (uav_tracks_from_obs, save_uav_positions, save_covered_num, target_tracks,  # noqa: F401
+                     save_target_positions, save_rollout)
 from .replay import DeviceReplayBuffer, PrioritizedDeviceReplayBuffer, transitions_from_rollout  # noqa: F401
 from .pmi_data import sample_pmi_pairs, pmi_contrastive_loss, pmi_batches  # noqa: F401
 from . import _lib  # noqa: F401

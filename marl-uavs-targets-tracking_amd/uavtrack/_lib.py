@@ -50,11 +50,13 @@ SIGNATURES = {
     "uavtrack_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.c_void_p]),
     "uavtrack_step_accumulate": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.c_void_p]),
     "uavtrack_step_many": (C.c_int, [C.c_void_p, C.c_int32] + [C.c_void_p] * 7 + [C.c_void_p]),
+    "uavtrack_step_many_autoreset": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64] + [C.c_void_p] * 7 + [C.c_void_p]),
     "uavtrack_run_greedy": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64] + [C.c_void_p] * 7 + [C.c_void_p]),
     "uavtrack_greedy_actions": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "uavtrack_set_actor_weights": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int32, C.c_void_p]),
     "uavtrack_actor_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "uavtrack_run_actor": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.c_int32] + [C.c_void_p] * 8 + [C.c_void_p]),
+    "uavtrack_set_target_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "uavtrack_pmi_pairs_scored": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),
     "uavtrack_kernel_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
 }
@@ -72,6 +74,8 @@ def load() -> C.CDLL:
                 f"`make -C marl-uavs-targets-tracking_amd/csrc`.  uavtrack has no CPU fallback.")
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
+            if os.environ.get("UAVTRACK_LIB_OLDER_OK") and not hasattr(lib, name):
+                continue              # A/B timing against an older build of the library (tools/sweep.py --lib)
             fn = getattr(lib, name)   # AttributeError if the library lacks a declared symbol
             fn.restype = res
             fn.argtypes = args

@@ -143,10 +143,36 @@ class BatchedUavEnv:
         self.info = {"terms": terms, "covered": covered}
         return obs, reward, done.bool()
 
+    def set_target_trace(self, buf: Optional[torch.Tensor]) -> None:
+        """Target positions after each step, [T, B, M, 2] (environment.py:150-153), written by every later stepping
+        call until replaced; None switches the output off."""
+        if buf is None:
+            _lib.check(self._lib.uavtrack_set_target_trace(self._h, None, 0), "uavtrack_set_target_trace")
+            return
+        if buf.dim() != 4 or not self._fits(buf, (buf.shape[0], self.B, self.M, 2), torch.float32):
+            raise ValueError(f"target trace must be a contiguous float32 [T, {self.B}, {self.M}, 2] tensor on {self.device}")
+        _lib.check(self._lib.uavtrack_set_target_trace(self._h, _ptr(buf), C.c_int32(buf.shape[0])), "uavtrack_set_target_trace")
+
+    def _with_targets(self, T: int, want: bool, o, launch):
+        """Run `launch()` with a [T, B, M, 2] target trace attached when asked; returns the trace (or None)."""
+        if not want:
+            launch()
+            return None
+        tp = self._reuse(o, "targets", (T, self.B, self.M, 2), torch.float32)
+        self.set_target_trace(tp)
+        try:
+            launch()
+        finally:
+            self.set_target_trace(None)
+        return tp
+
     def step_many(self, actions, want_obs: bool = True, want_terms: bool = True, want_ep_sums: bool = True,
-                  out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+                  out: Optional[Dict[str, torch.Tensor]] = None, want_targets: bool = False,
+                  auto_reset_seed: Optional[int] = None) -> Dict[str, torch.Tensor]:
         """T steps in one launch; `actions` is [T, B, N].  Pass the previous result as
-        `out` to reuse its buffers."""
+        `out` to reuse its buffers.  want_targets adds "targets" [T, B, M, 2], the target tracks of t_xy<ep>.csv.
+        auto_reset_seed: environments whose done flag fires are reset inside the launch (reset(seed, next episode)),
+        so the launch may span episodes (uavtrack_step_many_autoreset)."""
         a = torch.as_tensor(actions)
         T = int(a.shape[0])
         a = self._actions(a, (T, self.B, self.N))
@@ -161,10 +187,22 @@ class BatchedUavEnv:
         covered = buf("covered", (T, self.B), torch.int32)
         done = buf("done", (T, self.B), torch.uint8)
         ep = buf("ep_sums", (self.B, 5), torch.float32, want_ep_sums)
-        _lib.check(self._lib.uavtrack_step_many(self._h, C.c_int32(T), _ptr(a), _ptr(obs), _ptr(reward),
-                                                _ptr(terms), _ptr(covered), _ptr(done), _ptr(ep),
-                                                self._stream()), "uavtrack_step_many")
-        return dict(obs=obs, reward=reward, terms=terms, covered=covered, done=done, ep_sums=ep)
+        if auto_reset_seed is None:
+            launch = lambda: _lib.check(
+                self._lib.uavtrack_step_many(self._h, C.c_int32(T), _ptr(a), _ptr(obs), _ptr(reward), _ptr(terms), _ptr(covered),
+                                             _ptr(done), _ptr(ep), self._stream()), "uavtrack_step_many")
+        else:
+            launch = lambda: _lib.check(
+                self._lib.uavtrack_step_many_autoreset(self._h, C.c_int32(T), C.c_uint64(auto_reset_seed & (2 ** 64 - 1)), _ptr(a),
+                                                       _ptr(obs), _ptr(reward), _ptr(terms), _ptr(covered), _ptr(done), _ptr(ep),
+                                                       self._stream()), "uavtrack_step_many_autoreset")
+        tp = self._with_targets(T, want_targets, o, launch)
+        if auto_reset_seed is not None and self.cfg.horizon > 0:
+            self._episode += T // self.cfg.horizon + 1      # stay ahead of the episode numbers the device has used
+        res = dict(obs=obs, reward=reward, terms=terms, covered=covered, done=done, ep_sums=ep)
+        if tp is not None:
+            res["targets"] = tp
+        return res
 
     def bind_step_many(self, actions: torch.Tensor, out: Dict[str, torch.Tensor]):
         """A zero-argument callable that issues `uavtrack_step_many(actions -> out)` on the stream current NOW, with
@@ -251,7 +289,7 @@ class BatchedUavEnv:
         return a
 
     def run_greedy(self, T: int, seed: int = 0, want_obs: bool = True, want_terms: bool = True,
-                   want_actions: bool = True) -> Dict[str, torch.Tensor]:
+                   want_actions: bool = True, want_targets: bool = False) -> Dict[str, torch.Tensor]:
         """T closed-loop steps of the C-METHOD baseline (train.py:326-370) in one launch."""
         def buf(shape, dtype, want=True):
             return self._empty(shape, dtype) if want else None
@@ -262,10 +300,14 @@ class BatchedUavEnv:
         covered = buf((T, self.B), torch.int32)
         done = buf((T, self.B), torch.uint8)
         ep = buf((self.B, 5), torch.float32)
-        _lib.check(self._lib.uavtrack_run_greedy(self._h, C.c_int32(T), C.c_uint64(seed & (2 ** 64 - 1)), _ptr(acts),
-                                                 _ptr(obs), _ptr(reward), _ptr(terms), _ptr(covered), _ptr(done),
-                                                 _ptr(ep), self._stream()), "uavtrack_run_greedy")
-        return dict(actions=acts, obs=obs, reward=reward, terms=terms, covered=covered, done=done, ep_sums=ep)
+        tp = self._with_targets(T, want_targets, None, lambda: _lib.check(
+            self._lib.uavtrack_run_greedy(self._h, C.c_int32(T), C.c_uint64(seed & (2 ** 64 - 1)), _ptr(acts), _ptr(obs),
+                                          _ptr(reward), _ptr(terms), _ptr(covered), _ptr(done), _ptr(ep), self._stream()),
+            "uavtrack_run_greedy"))
+        res = dict(actions=acts, obs=obs, reward=reward, terms=terms, covered=covered, done=done, ep_sums=ep)
+        if tp is not None:
+            res["targets"] = tp
+        return res
 
     # ---- the learner's shared actor on the device (actor_critic.py:85-98, 138-148) ----
     def set_actor(self, actor) -> None:
@@ -300,7 +342,8 @@ class BatchedUavEnv:
         return (a, probs) if want_probs else a
 
     def run_actor(self, T: int, obs_in: torch.Tensor, seed: int = 0, mode: int = _lib.ACTOR_SAMPLE,
-                  want_terms: bool = True, out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+                  want_terms: bool = True, out: Optional[Dict[str, torch.Tensor]] = None,
+                  want_targets: bool = False) -> Dict[str, torch.Tensor]:
         """T closed-loop steps of actor + environment (the rollout of train.operate_epoch, train.py:160-192) in
         one launch.  obs_in [B, N, 12] is what the policy sees first (reset()'s return or the last obs)."""
         if obs_in.shape != (self.B, self.N, _lib.OBS_DIM) or obs_in.dtype != torch.float32 \
@@ -317,11 +360,14 @@ class BatchedUavEnv:
         covered = buf("covered", (T, self.B), torch.int32)
         done = buf("done", (T, self.B), torch.uint8)
         ep = buf("ep_sums", (self.B, 5), torch.float32)
-        _lib.check(self._lib.uavtrack_run_actor(self._h, C.c_int32(T), C.c_uint64(seed & (2 ** 64 - 1)), C.c_int32(mode),
-                                                _ptr(obs_in), _ptr(acts), _ptr(obs), _ptr(reward), _ptr(terms),
-                                                _ptr(covered), _ptr(done), _ptr(ep), self._stream()),
-                   "uavtrack_run_actor")
-        return dict(actions=acts, obs=obs, reward=reward, terms=terms, covered=covered, done=done, ep_sums=ep)
+        tp = self._with_targets(T, want_targets, o, lambda: _lib.check(
+            self._lib.uavtrack_run_actor(self._h, C.c_int32(T), C.c_uint64(seed & (2 ** 64 - 1)), C.c_int32(mode), _ptr(obs_in),
+                                         _ptr(acts), _ptr(obs), _ptr(reward), _ptr(terms), _ptr(covered), _ptr(done), _ptr(ep),
+                                         self._stream()), "uavtrack_run_actor"))
+        res = dict(actions=acts, obs=obs, reward=reward, terms=terms, covered=covered, done=done, ep_sums=ep)
+        if tp is not None:
+            res["targets"] = tp
+        return res
 
     def pmi_pairs_scored(self) -> int:
         """Neighbour pairs the PMI network has scored so far (synchronises the stream)."""

@@ -1,9 +1,11 @@
 """Trajectory / result export in the reference's formats, from what the batched
 environment already returns: the last three observation entries are x/dc, y/dc, a/Na (uav.py:154),
-so a rollout's `obs[T, B, N, 12]` carries every UAV track; target tracks need the state snapshots.
+so a rollout's `obs[T, B, N, 12]` carries every UAV track; the target tracks are the optional `targets[T, B, M, 2]`
+output of the stepping calls (step_many(..., want_targets=True); uavtrack_set_target_trace).
 
     u_xy<ep>.csv            rows `x,y`: np.array([xs, ys]).transpose().reshape(-1, 2) with xs, ys of
                             shape [T][N]  ->  UAV-major, then step           (environment.py:229-238)
+    t_xy<ep>.csv            the same layout for the targets                  (environment.py:232-238)
     covered_target_num<ep>.csv   one count per step                          (environment.py:240-244)
 """
 from __future__ import annotations
@@ -27,6 +29,33 @@ def save_uav_positions(save_dir: str, epoch_i, xs, ys) -> str:
     os.makedirs(os.path.dirname(path), exist_ok=True)
     np.savetxt(path, u_xy.reshape(-1, 2), delimiter=",", header="x,y", comments="")
     return path
+
+
+def target_tracks(targets, env_index: int = 0):
+    """targets [T, B, M, 2] (tensor or array) -> (xs [T, M], ys [T, M]) for one environment."""
+    t = targets[:, env_index]
+    t = t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
+    return t[..., 0], t[..., 1]
+
+
+def save_target_positions(save_dir: str, epoch_i, xs, ys) -> str:
+    """Same file as Environment.save_position writes for the targets (environment.py:232-238)."""
+    t_xy = np.array([np.asarray(xs), np.asarray(ys)]).transpose()          # [M, T, 2]
+    path = os.path.join(save_dir, "t_xy", "t_xy" + str(epoch_i) + ".csv")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    np.savetxt(path, t_xy.reshape(-1, 2), delimiter=",", header="x,y", comments="")
+    return path
+
+
+def save_rollout(save_dir: str, epoch_i, result, dc: float, env_index: int = 0):
+    """Everything Environment.save_position + save_covered_num write for one environment of a batched rollout
+    (`result` = step_many / run_actor / run_greedy output with want_targets=True).  Returns the three paths."""
+    xs, ys = uav_tracks_from_obs(result["obs"], dc, env_index)
+    paths = [save_uav_positions(save_dir, epoch_i, xs, ys)]
+    txs, tys = target_tracks(result["targets"], env_index)
+    paths.append(save_target_positions(save_dir, epoch_i, txs, tys))
+    paths.append(save_covered_num(save_dir, epoch_i, result["covered"], env_index))
+    return paths
 
 
 def save_covered_num(save_dir: str, epoch_i, covered, env_index: int = 0) -> str:

@@ -169,7 +169,12 @@ def random_pmi_state_dict(hidden, seed):
 
 
 @pytest.mark.parametrize("N,M,B,hidden,box", [(20, 10, 128, 128, 2000.0), (20, 10, 96, 128, 500.0), (50, 25, 24, 128, 2000.0),
-                                              (20, 10, 64, 64, 700.0), (7, 4, 50, 128, 600.0), (5, 3, 40, 64, 2000.0)])
+                                              (20, 10, 64, 64, 700.0), (7, 4, 50, 128, 600.0), (5, 3, 40, 64, 2000.0),
+                                              # PMINetwork takes any hidden_dim (PMINet.py:19): other multiples of 32, a width
+                                              # that is padded (100 -> 128), one past the register-stationary limit, and
+                                              # more than 64 UAVs (multi-word neighbour records)
+                                              (20, 10, 64, 96, 700.0), (20, 10, 48, 100, 700.0), (10, 10, 40, 32, 600.0),
+                                              (20, 10, 32, 200, 600.0), (70, 5, 6, 64, 900.0)])
 def test_pmi_reward_teacher_forced_vs_oracle(uavtrack, pmi_state_dict, N, M, B, hidden, box):
     """MAAC-R (BASELINE configs[2]): PMI-softmax weighted neighbour rewards (uav.py:262-291) with the
     BatchNorm-folded PMINetwork on the matrix cores, against the unfolded fp64 oracle."""
@@ -519,6 +524,147 @@ def test_baseline_shapes_full_size(uavtrack, pmi_state_dict, name, kw, pmi, step
     assert excluded <= 0.01 * compared, f"{name}: {excluded} of {compared} env-steps on a knife edge (> 1 %)"
     assert int(env.get_state()["step_count"].min()) == steps
     env.close()
+
+
+def test_target_trace_and_reference_csv_export(uavtrack, tmp_path):
+    """SURVEY 8f-4 on the device: the [T, B, M, 2] target trace (uavtrack_set_target_trace) equals the target state
+    after every single step, fused == stepwise; and the three CSV files written from a BATCHED rollout for environment
+    b (export.save_rollout) are byte-identical to what the reference-shaped B = 1 adapter's save_position /
+    save_covered_num (environment.py:229-244) writes for the same episode."""
+    B, N, M, T = 37, 5, 3, 25
+    cfg = uavtrack.EnvConfig(n_envs=B, n_uav=N, m_targets=M)
+    a, b = uavtrack.BatchedUavEnv(cfg), uavtrack.BatchedUavEnv(cfg)
+    a.reset(seed=5); b.reset(seed=5)
+    act = torch.randint(0, 12, (T, B, N), dtype=torch.int32, device="cuda", generator=torch.Generator("cuda").manual_seed(1))
+    res = a.step_many(act, want_targets=True)
+    assert res["targets"].shape == (T, B, M, 2)
+    for t in range(T):
+        b.step(act[t])
+        st = b.get_state()
+        assert torch.equal(res["targets"][t, ..., 0], st["tx"]) and torch.equal(res["targets"][t, ..., 1], st["ty"]), t
+    # the trace is off again afterwards, and a too-short buffer is refused rather than overrun
+    a.set_target_trace(torch.empty(3, B, M, 2, device="cuda"))
+    with pytest.raises(RuntimeError, match="target-trace buffer"):
+        a.step_many(act[:4])
+    a.set_target_trace(None)
+    # ---- CSV files: batched export of environment `bi` vs the adapter driven step by step from the same state
+    import filecmp
+    from uavtrack.export import save_rollout
+    bi = 11
+    c = uavtrack.BatchedUavEnv(cfg); c.reset(seed=5)
+    st0 = c.get_state()
+    ref_cfg = {"environment": {"n_uav": N, "m_targets": M, "x_max": 2000, "y_max": 2000, "na": 12},
+               "uav": {"dt": 1, "v_max": 20, "h_max": 6, "dc": 500, "dp": 200, "alpha": 0.6, "beta": 0.2, "gamma": 0.2},
+               "target": {"v_max": 5, "h_max": 6}, "cooperative": 0}
+    one = uavtrack.Environment(n_uav=N, m_targets=M, x_max=2000, y_max=2000, na=12)
+    one.reset(ref_cfg)
+    one._env.set_state(**{k: v[bi:bi + 1] for k, v in st0.items() if k != "step_count"})
+    for t in range(T):
+        one.step(ref_cfg, None, act[t, bi].cpu().numpy().tolist())
+    d1, d2 = tmp_path / "batched", tmp_path / "adapter"
+    for d in (d1, d2):
+        for sub in ("u_xy", "t_xy", "covered_target_num"):
+            (d / sub).mkdir(parents=True)
+    paths = save_rollout(str(d1), 3, res, dc=cfg.dc, env_index=bi)
+    one.save_position(str(d2), 3)
+    one.save_covered_num(str(d2), 3)
+    assert len(paths) == 3
+    for sub, name in (("t_xy", "t_xy3.csv"), ("covered_target_num", "covered_target_num3.csv")):
+        assert filecmp.cmp(d1 / sub / name, d2 / sub / name, shallow=False), name
+    # UAV tracks come back from obs[..., 9:11] * dc: the file agrees with the adapter's to fp32 rounding of x / dc * dc
+    u1 = np.loadtxt(d1 / "u_xy" / "u_xy3.csv", delimiter=",", skiprows=1)
+    u2 = np.loadtxt(d2 / "u_xy" / "u_xy3.csv", delimiter=",", skiprows=1)
+    assert u1.shape == u2.shape == (N * T, 2)
+    np.testing.assert_allclose(u1, u2, rtol=2e-7, atol=0)
+
+
+def test_pmi_training_gather_on_device_rollout(uavtrack):
+    """SURVEY 8f-3 on the device: sample_pmi_pairs on a real rollout's observation history (the tensor
+    train.operate_epoch hands to PMINetwork.train_pmi, train.py:183 order) returns, for its own drawn indices,
+    exactly the rows the reference's copy loop selects (PMINet.py:78-84: selected[i] = data[t_i, (u_i0, u_i1)]),
+    and its mini-batches are the slices train_pmi iterates (PMINet.py:87-92)."""
+    from uavtrack.pmi_data import pmi_batches, pmi_contrastive_loss, sample_pmi_pairs
+    B, N, M, T = 16, 10, 10, 30
+    env = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(n_envs=B, n_uav=N, m_targets=M, cooperative=0.3))
+    env.reset(seed=4)
+    act = torch.randint(0, 12, (T, B, N), dtype=torch.int32, device="cuda")
+    obs = env.step_many(act)["obs"]                                    # [T, B, N, 12] on the device
+    g = torch.Generator(device="cuda").manual_seed(9)
+    b2 = 512
+    sel, t_idx, u_idx = sample_pmi_pairs(obs, N, b2, generator=g)
+    assert sel.is_cuda and sel.shape == (b2, 2, 12)
+    # the reference's loop, restated on the host over the same flattened history and the same indices
+    data = obs.reshape(-1, N, 12).cpu().numpy()                        # train_data.view(timesteps, n_uav, 12)
+    ti, ui = t_idx.cpu().numpy(), u_idx.cpu().numpy()
+    assert ti.min() >= 0 and ti.max() < T * B and ui.min() >= 0 and ui.max() < N
+    want = np.zeros((b2, 2, 12), np.float32)
+    for i in range(b2):
+        want[i] = data[ti[i], ui[i]]
+    np.testing.assert_array_equal(sel.cpu().numpy(), want)
+    batches = list(pmi_batches(sel, 128))
+    assert len(batches) == b2 // 128
+    for k, (x12, x13) in enumerate(batches):
+        np.testing.assert_array_equal(x12.cpu().numpy(), want[k * 128:(k + 1) * 128, 0])
+        np.testing.assert_array_equal(x13.cpu().numpy(), want[k * 128:(k + 1) * 128, 1])
+    # CustomLoss (PMINet.py:15-17) in its literal form on the device outputs of a scorer-shaped net
+    net = uavtrack.make_pmi_net(64).cuda().eval()
+    with torch.no_grad():
+        o1, o2 = net(batches[0][0]), net(batches[0][1])
+        lit = torch.mean(torch.log(1 + torch.exp(-o1)) + torch.log(1 + torch.exp(o2)))
+    torch.testing.assert_close(pmi_contrastive_loss(o1, o2), lit, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("mode,dim", [("raw", 2), ("mean", 2), ("pmi", 2), ("raw", 3)])
+def test_auto_reset_equals_manual_episode_turnover(uavtrack, pmi_state_dict, mode, dim):
+    """uavtrack_step_many_autoreset (SURVEY 8d "auto-reset at done"): environments reach their horizon at DIFFERENT
+    steps of one launch; each is reset in place to uavtrack_reset(seed, its episode + 1).  The launch must equal, bit
+    for bit, single steps with the finished environments spliced to the states a real uavtrack_reset produces."""
+    B, N, M, T, H = 40, 20, 10, 23, 7
+    kw = dict(n_envs=B, n_uav=N, m_targets=M, cooperative=0.0 if mode == "raw" else 0.3, horizon=H, env_offset=500,
+              dim=dim, nc=3 if dim == 3 else 1)
+    if mode == "pmi":
+        kw["reward_mode"] = uavtrack.RewardMode.PMI
+    cfg = uavtrack.EnvConfig(**kw)
+    a, b, c = (uavtrack.BatchedUavEnv(cfg) for _ in range(3))
+    if mode == "pmi":
+        for e in (a, b):
+            e.set_pmi(pmi_state_dict)
+    a.reset(seed=3, episode=5); b.reset(seed=3, episode=5)
+    start = torch.arange(B, dtype=torch.int32, device="cuda") % H                  # environments at different episode positions
+    for e in (a, b):
+        st = e.get_state()
+        e.set_state(**{k: v for k, v in st.items() if k != "step_count"}, step_count=start)
+    na = 12 * (3 if dim == 3 else 1)
+    act = torch.randint(0, na, (T, B, N), dtype=torch.int32, device="cuda", generator=torch.Generator("cuda").manual_seed(2))
+    fused = a.step_many(act, auto_reset_seed=99, want_targets=True)
+    episode = torch.full((B,), 5, dtype=torch.int64)
+    saw = 0
+    for t in range(T):
+        obs, rew, done = b.step(act[t])
+        assert torch.equal(obs, fused["obs"][t]) and torch.equal(rew, fused["reward"][t]), (mode, t)
+        assert torch.equal(b.info["terms"], fused["terms"][t]) and torch.equal(b.info["covered"], fused["covered"][t])
+        assert torch.equal(done, fused["done"][t].bool())
+        st = b.get_state()
+        assert torch.equal(st["tx"], fused["targets"][t, ..., 0]) and torch.equal(st["ty"], fused["targets"][t, ..., 1])
+        d = done.cpu()
+        if d.any():                                       # splice the finished environments to their next episode's reset state
+            saw += int(d.sum())
+            episode[d] += 1
+            for ep in episode[d].unique().tolist():
+                c.reset(seed=99, episode=int(ep))
+                fresh = c.get_state()
+                pick = (d & (episode == ep)).cuda()
+                for k in st:
+                    st[k][pick] = fresh[k][pick]
+            b.set_state(**{k: v for k, v in st.items() if k != "step_count"}, step_count=st["step_count"])
+    assert saw >= 3 * B - B                                # everybody turned over at least twice
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    # the next automatic reset continues the per-environment episode count: one more horizon, same check on the state
+    more = torch.randint(0, na, (H, B, N), dtype=torch.int32, device="cuda")
+    a.step_many(more, auto_reset_seed=99)
+    assert int(a.get_state()["step_count"].max()) < H
 
 
 def test_compat_environment_reference_call_shapes(uavtrack):
@@ -893,8 +1039,8 @@ def test_create_destroy_does_not_leak_and_errors_are_reported(uavtrack, pmi_stat
         env.step(torch.zeros(4, 5, dtype=torch.int32))
     with pytest.raises((RuntimeError, ValueError)):
         env.step(torch.zeros(4, 6, dtype=torch.int32))                     # wrong shape
-    with pytest.raises(RuntimeError, match="hidden 96 not built"):
-        env.set_pmi(random_pmi_state_dict(96, 0))
+    with pytest.raises(RuntimeError, match="hidden 300 outside"):
+        env.set_pmi(random_pmi_state_dict(300, 0))
     with pytest.raises(ValueError, match="do not match"):
         env.set_actor({"fc1.weight": torch.zeros(8, 11), "fc1.bias": torch.zeros(8),
                        "fc2.weight": torch.zeros(12, 8), "fc2.bias": torch.zeros(12)})
