@@ -116,6 +116,7 @@ struct Geometry {
     int groups = 0;       // workgroups
     size_t lds_bytes = 0;
     int specialised = 0;
+    int lone = 0;         // single-wave groups on a grid of at most two waves per SIMD: the LONE kernel variant
 };
 
 }  // namespace uavtrack

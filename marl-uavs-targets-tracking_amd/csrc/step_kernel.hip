@@ -45,9 +45,9 @@
 #ifndef UAVTRACK_UNROLL_U
 #define UAVTRACK_UNROLL_U 5
 #endif
-// peer-table copy select of the sweep: 1 = bit test + multiply-add on a per-lane mask, 0 = compare + select
-#ifndef UAVTRACK_SEL_BITS
-#define UAVTRACK_SEL_BITS 0
+// Peer rows the sweeps' LDS reads run ahead of their use in the lone-wavefront (small-grid) kernel variant
+#ifndef UAVTRACK_LDS_PREFETCH
+#define UAVTRACK_LDS_PREFETCH 2
 #endif
 #ifndef UAVTRACK_BRANCHFREE
 #define UAVTRACK_BRANCHFREE 1
@@ -152,6 +152,22 @@ __device__ __forceinline__ void sincos_any(float h, float *s, float *c)
     else sincosf(h, s, c);
 }
 
+// The two barriers of a step.  A single-wavefront workgroup (LONE) needs neither the barrier nor the LDS drain in
+// front of it: a wavefront's LDS operations execute in program order, so its reads see its own lanes' earlier writes;
+// only the compiler must be kept from moving them across.
+// (A macro, not a function: this file is built with -fno-convergent-functions, and a barrier wrapped in a function of
+// ours would lose its convergence -- the optimiser then moved it relative to divergent code in one kernel variant.)
+#define UAVTRACK_STEP_BARRIER()                                          \
+    do {                                                                 \
+        if (LONE) {                                                      \
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       \
+            __builtin_amdgcn_wave_barrier();                             \
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
+        } else {                                                         \
+            __syncthreads();                                             \
+        }                                                                \
+    } while (0)
+
 // uniform base + zero-extended 32-bit per-lane byte offset: the form the global_load/store `saddr` encoding takes
 template <typename T>
 __device__ __forceinline__ T *at(T *base, unsigned byte_off)
@@ -197,7 +213,7 @@ __device__ __forceinline__ void uav_store(float4 *rows, int j, float x, float y,
 // Pair sweeps of one UAV, fast path: two agents per packed instruction, no per-agent
 // `j != i` test (self terms are subtracted afterwards).  The uav.py:165/179 weight is 1
 // here (see sweep_weighted).
-template <int N_, int M_, bool Z3, bool NB>
+template <int N_, int M_, bool Z3, bool NB, int PF>
 __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, int i,
                                            const float4 *__restrict__ rowNew, const float4 *__restrict__ rowOld,
                                            const float4 *__restrict__ trow, const v2f *__restrict__ tzrow,
@@ -216,9 +232,29 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
     // ---- targets: observe_target (<= dp), tracking reward (<= dp), coverage (< dp)
     v2f sx = splat(0.f), sy = splat(0.f), sc = splat(0.f), ss = splat(0.f), cnt = splat(0.f), trk = splat(0.f);
     v2f cov = splat(0.f);   // coverage (d < dp, strict) of the pair's two targets as base-4 digits: cov = 4 * cov + {0, 1}
+    // PF > 0: table rows are requested PF peer rows ahead of their use and pinned there (sched_barrier lets ALU work
+    // cross, LDS reads not): a wavefront that runs alone on its SIMD -- the small-grid geometry -- has nothing else to
+    // cover an LDS round trip with (-6 % at 4096 envs; at a chip-filling batch the extra registers cost 5 %, so the
+    // 4-wave groups keep PF = 0).  Specialised planar shapes only.
+    constexpr int QM = M_ > 0 ? (M_ + 1) / 2 : 1, QN = N_ > 0 ? (N_ + 1) / 2 : 1;
+    constexpr bool kPrefetch = PF > 0 && N_ > 0 && M_ > 0 && QN <= 10 && QM <= 5 && !Z3;
+    float4 Q0[QM], Q1[QM], PN0[QN], PM0[QN], PM1[QN];
+    v2f PM2[QN];
+    auto fetch_row = [&](int jq) {
+        const float4 *rq = (2 * jq < i) ? rowNew : rowOld;
+        PN0[jq] = rowNew[jq * 6]; PM0[jq] = rq[jq * 6]; PM1[jq] = rq[jq * 6 + 1];
+        PM2[jq] = *reinterpret_cast<const v2f *>(&rq[jq * 6 + 2]);
+    };
+    if (kPrefetch) {
+#pragma unroll
+        for (int kp = 0; kp < QM; ++kp) { Q0[kp] = trow[kp * 2]; Q1[kp] = trow[kp * 2 + 1]; }
+#pragma unroll
+        for (int jq = 0; jq < PF && jq < QN; ++jq) fetch_row(jq);
+        __builtin_amdgcn_sched_barrier(0x407);
+    }
 #pragma unroll UAVTRACK_UNROLL_T
     for (int kp = 0; kp < MP; ++kp) {
-        const float4 q0 = trow[kp * 2], q1 = trow[kp * 2 + 1];
+        const float4 q0 = kPrefetch ? Q0[kPrefetch ? kp : 0] : trow[kp * 2], q1 = kPrefetch ? Q1[kPrefetch ? kp : 0] : trow[kp * 2 + 1];
         const v2f dx = (v2f){q0.x, q0.y} - xi2, dy = (v2f){q0.z, q0.w} - yi2;
         v2f d2 = pk_fma(dy, dy, dx * dx);
         if (Z3) { const v2f dz = tzrow[kp] - zi2; d2 = pk_fma(dz, dz, d2); }
@@ -233,7 +269,7 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
         sc = pk_fma(mm, (v2f){q1.x, q1.y}, sc);
         ss = pk_fma(mm, (v2f){q1.z, q1.w}, ss);
         cnt += mm;
-        trk = pk_fma(mm, pk_fma(dist, splat(-p.inv_dp), splat(2.0f)), trk);   // 1 + (dp - d)/dp
+        trk = pk_fma(mm, dist, trk);                 // sum m d: tracking reward sum m (1 + (dp - d)/dp) = 2 cnt - (sum m d)/dp
         cov = pk_fma(cov, splat(4.0f), pk_le_mask(d2, nscale, p.lt_dp2));
         if (kp % kCovPairs == kCovPairs - 1 || kp == MP - 1) {       // 12 digits < 2^24: exact in fp32
             const unsigned bits = (unsigned)cov.x | ((unsigned)cov.y << 1);
@@ -242,7 +278,7 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
         }
     }
     a.cntT = cnt.x + cnt.y; a.iwT = a.cntT;
-    a.sxT = sx.x + sx.y; a.syT = sy.x + sy.y; a.trk = trk.x + trk.y;
+    a.sxT = sx.x + sx.y; a.syT = sy.x + sy.y; a.trk = fmaf(-(trk.x + trk.y), p.inv_dp, 2.0f * a.cntT);
     // sum_k m (c_k r - c_i) = r sum_k m c_k - c_i cnt  (r = target speed / uav speed, uav.py:116)
     a.scT = fmaf(sc.x + sc.y, p.vratio, -ci * a.cntT);
     a.ssT = fmaf(ss.x + ss.y, p.vratio, -si * a.cntT);
@@ -251,23 +287,18 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
     //      sequential view (<= dc)
     sx = splat(0.f); sy = splat(0.f); sc = splat(0.f); ss = splat(0.f); cnt = splat(0.f);
     v2f sa = splat(0.f), dup = splat(0.f);
-#if UAVTRACK_SEL_BITS
-    unsigned selbits = (1u << ((i + 1) >> 1)) - 1u;            // bit jp set iff 2 jp < i   (i <= 63 here: NP <= 32 rows)
-    asm("" : "+v"(selbits));   // opaque: the optimiser would turn the bit tests back into compare masks held in (spilled) SGPRs
-    const int dsel = (int)(rowNew - rowOld);                   // +-3 float4
-#endif
     constexpr bool NBF = NB && N_ > 0 && (N_ + 1) / 2 <= kCovPairs;
     v2f nbf = splat(0.f);
 #pragma unroll UU
     for (int jp = 0; jp < NP; ++jp) {
-#if UAVTRACK_SEL_BITS
-        // post-move copy iff 2 jp < i: bit jp of a per-lane mask, as an address offset (no compare masks to keep in SGPRs)
-        const float4 *rs = rowOld + (int)((selbits >> jp) & 1u) * dsel;   // one select serves pose, heading, action, z
-#else
         const float4 *rs = (2 * jp < i) ? rowNew : rowOld;   // one select serves pose, heading, action, z
-#endif
-        const float4 n0 = rowNew[jp * 6];
-        const float4 m0 = rs[jp * 6], m1 = rs[jp * 6 + 1], m2 = rs[jp * 6 + 2];
+        if (kPrefetch) {
+            if (jp + PF < NP) fetch_row(jp + PF);
+            __builtin_amdgcn_sched_barrier(0x407);
+        }
+        const float4 n0 = kPrefetch ? PN0[kPrefetch ? jp : 0] : rowNew[jp * 6];
+        const float4 m0 = kPrefetch ? PM0[kPrefetch ? jp : 0] : rs[jp * 6], m1 = kPrefetch ? PM1[kPrefetch ? jp : 0] : rs[jp * 6 + 1];
+        const float4 m2 = kPrefetch ? make_float4(PM2[kPrefetch ? jp : 0].x, PM2[kPrefetch ? jp : 0].y, 0.f, 0.f) : rs[jp * 6 + 2];
         const v2f dxn = (v2f){n0.x, n0.y} - xi2, dyn = (v2f){n0.z, n0.w} - yi2;
         const v2f dxm = (v2f){m0.x, m0.y} - xi2, dym = (v2f){m0.z, m0.w} - yi2;
         v2f d2n = pk_fma(dyn, dyn, dxn * dxn), d2m = pk_fma(dym, dym, dxm * dxm);
@@ -391,7 +422,8 @@ __device__ __forceinline__ void sweep_weighted(const StepParams &p, int N, int M
 // consumes and the benchmark workload; the nullable-pointer tests and their SGPR flags then fold away.
 // EXTRAS: the launch uses the rarely wanted per-step extras (target trace, automatic reset); compiled out otherwise --
 // their tests and parameters cost the plain rollout ~10 % when they sat in the same instantiation.
-template <int N_, int M_, int MODE, bool Z3, int POLICY, bool ALLOUT = false, bool EXTRAS = false>
+// LONE: built for single-wavefront workgroups on a grid of at most a few waves per SIMD (plan_geometry's small grid).
+template <int N_, int M_, int MODE, bool Z3, int POLICY, bool ALLOUT = false, bool EXTRAS = false, bool LONE = false>
 __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams p)
 {
     constexpr bool GREEDY = POLICY == kPolicyGreedy;
@@ -632,7 +664,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             if (i == 0)
                 for (int w = 0; w < CW; ++w) covw[cbuf + e * CW + w] = 0;
         }
-        __syncthreads();
+        UAVTRACK_STEP_BARRIER();
 
         // ---- P2: pair sweeps
         float tt = 0, bp = 0, dupn = 0, raw = 0;
@@ -662,7 +694,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                         nbmask |= (unsigned long long)(d2 <= p.dp2 ? 1u : 0u) << j;
                     }
             } else {
-                sweep_fast<N_, M_, Z3, kMask>(p, N, M, i, rowNew, rowOld, tenv, tzrow, covw, cbuf + e * CW,
+                sweep_fast<N_, M_, Z3, kMask, LONE ? UAVTRACK_LDS_PREFETCH : 0>(p, N, M, i, rowNew, rowOld, tenv, tzrow, covw, cbuf + e * CW,
                                               x, y, z, c, s, ai, xo, yo, zo, co, so, ao, acc, nbmask);
             }
 
@@ -724,7 +756,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             raw = p.alpha * tt + p.beta * bp + p.gamma * dupn;
             if (MODE != UAVTRACK_REWARD_RAW) rawl[e * (N + 1) + i] = raw;
         }
-        __syncthreads();
+        UAVTRACK_STEP_BARRIER();
 
         // ---- P4: cooperative reward, coverage, outputs
         if (active) {
@@ -990,29 +1022,33 @@ size_t lds_bytes_for(int E, int N, int M, bool z3)
 
 using KernelFn = void (*)(const StepParams);
 
-template <int N_, int M_, int POLICY, bool ALLOUT, bool EXTRAS>
+template <int N_, int M_, int POLICY, bool ALLOUT, bool EXTRAS, bool LONE = false>
 KernelFn pick_reward(int mode, bool z3)
 {
     constexpr bool PLANAR_ONLY = POLICY == kPolicyGreedy;      // the baseline policy is planar and runs with MAAC / MAAC-G
     if (z3 && !PLANAR_ONLY) {
         switch (mode) {
-        case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, !PLANAR_ONLY, POLICY, ALLOUT, EXTRAS>;
-        case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, PLANAR_ONLY ? UAVTRACK_REWARD_RAW : UAVTRACK_REWARD_PMI, !PLANAR_ONLY, POLICY, ALLOUT, EXTRAS>;
-        default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, !PLANAR_ONLY, POLICY, ALLOUT, EXTRAS>;
+        case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, !PLANAR_ONLY, POLICY, ALLOUT, EXTRAS, LONE>;
+        case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, PLANAR_ONLY ? UAVTRACK_REWARD_RAW : UAVTRACK_REWARD_PMI, !PLANAR_ONLY, POLICY, ALLOUT, EXTRAS, LONE>;
+        default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, !PLANAR_ONLY, POLICY, ALLOUT, EXTRAS, LONE>;
         }
     }
     switch (mode) {
-    case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, false, POLICY, ALLOUT, EXTRAS>;
-    case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, PLANAR_ONLY ? UAVTRACK_REWARD_RAW : UAVTRACK_REWARD_PMI, false, POLICY, ALLOUT, EXTRAS>;
-    default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, false, POLICY, ALLOUT, EXTRAS>;
+    case UAVTRACK_REWARD_MEAN: return rollout_kernel<N_, M_, UAVTRACK_REWARD_MEAN, false, POLICY, ALLOUT, EXTRAS, LONE>;
+    case UAVTRACK_REWARD_PMI:  return rollout_kernel<N_, M_, PLANAR_ONLY ? UAVTRACK_REWARD_RAW : UAVTRACK_REWARD_PMI, false, POLICY, ALLOUT, EXTRAS, LONE>;
+    default:                   return rollout_kernel<N_, M_, UAVTRACK_REWARD_RAW, false, POLICY, ALLOUT, EXTRAS, LONE>;
     }
 }
 
 // Instantiations: pre-sampled actions with every output and no extras (the learner's rollout, the benchmark);
 // any policy without extras; any policy with them.
 template <int N_, int M_>
-KernelFn pick_mode(int mode, bool z3, int policy, bool allout, bool extras)
+KernelFn pick_mode(int mode, bool z3, int policy, bool allout, bool extras, bool lone)
 {
+    if constexpr (N_ > 0 && N_ <= 20 && M_ <= 10) {       // the shapes sweep_fast's prefetch is written for
+        if (policy == kPolicyGiven && allout && !extras && lone && !z3 && mode != UAVTRACK_REWARD_PMI)
+            return pick_reward<N_, M_, kPolicyGiven, true, false, true>(mode, false);
+    }
     if (policy == kPolicyGreedy)
         return extras ? pick_reward<N_, M_, kPolicyGreedy, false, true>(mode, z3) : pick_reward<N_, M_, kPolicyGreedy, false, false>(mode, z3);
     if (policy == kPolicyActor)
@@ -1022,15 +1058,15 @@ KernelFn pick_mode(int mode, bool z3, int policy, bool allout, bool extras)
 }
 
 KernelFn pick_kernel(int N, int M, int mode, bool z3, int *specialised, int policy = kPolicyGiven, bool allout = false,
-                     bool extras = false)
+                     bool extras = false, bool lone = false)
 {
     *specialised = 1;
-    if (N == 20 && M == 10) return pick_mode<20, 10>(mode, z3, policy, allout, extras);
-    if (N == 50 && M == 25) return pick_mode<50, 25>(mode, z3, policy, allout, extras);
-    if (N == 10 && M == 10) return pick_mode<10, 10>(mode, z3, policy, allout, extras);
-    if (N == 5 && M == 3) return pick_mode<5, 3>(mode, z3, policy, allout, extras);
+    if (N == 20 && M == 10) return pick_mode<20, 10>(mode, z3, policy, allout, extras, lone);
+    if (N == 50 && M == 25) return pick_mode<50, 25>(mode, z3, policy, allout, extras, lone);
+    if (N == 10 && M == 10) return pick_mode<10, 10>(mode, z3, policy, allout, extras, lone);
+    if (N == 5 && M == 3) return pick_mode<5, 3>(mode, z3, policy, allout, extras, lone);
     *specialised = 0;
-    return pick_mode<0, 0>(mode, z3, policy, allout, extras);
+    return pick_mode<0, 0>(mode, z3, policy, allout, extras, lone);
 }
 
 }  // namespace
@@ -1074,16 +1110,20 @@ Geometry plan_geometry(const uavtrack_config &cfg, int n_simd)
         for (int wgs : kLarge)
             if (feasible(wgs) && util_of(wgs) > best_util) best_util = util_of(wgs);
         bool small_grid = false;
+        long waves64 = 0;
         // (MAAC-R keeps the larger groups: its pair emission costs one global atomic per workgroup-step, and
         // four times the workgroups measured 15.8 instead of 5.2 us per step at 4096 envs)
         if (feasible(64) && cfg.reward_mode != UAVTRACK_REWARD_PMI) {
             const long waves = (cfg.n_envs + envs_of(64) - 1) / envs_of(64);
             small_grid = waves <= 3L * (n_simd > 0 ? n_simd : 1024);
+            waves64 = waves;
         }
         // (the band is a little wider on a small grid: N = 10 at 4096 envs measured 0.409 ms with
         // 60/64 lanes in use against 0.435 ms with 250/256)
         for (int wgs : small_grid ? kSmall : kLarge)
             if (feasible(wgs) && util_of(wgs) >= best_util - (small_grid ? 0.07 : 0.05)) { best = wgs; break; }
+        // at most two waves per SIMD: the LONE kernel variant (deep LDS prefetch, ~215 registers: two resident waves)
+        g.lone = small_grid && best == 64 && waves64 <= 2L * (n_simd > 0 ? n_simd : 1024);
     }
     if (!best) return g;
     g.wgs = best;
@@ -1106,7 +1146,7 @@ hipError_t launch_rollout(const uavtrack_env *env, const StepParams &p, hipStrea
     int spec = 0;
     const bool allout = p.obs && p.reward && p.terms && p.covered && p.done;
     const bool extras = p.auto_reset || p.tpos;
-    KernelFn fn = pick_kernel(p.N, p.M, env->cfg.reward_mode, env->cfg.dim == 3, &spec, policy, allout, extras);
+    KernelFn fn = pick_kernel(p.N, p.M, env->cfg.reward_mode, env->cfg.dim == 3, &spec, policy, allout, extras, env->geo.lone != 0);
     const Geometry &g = env->geo;
     StepParams q = p;
     if (policy == kPolicyActor) q.actor_lds_off = (int32_t)g.lds_bytes;

@@ -3,7 +3,7 @@
 # headline bench configuration.  Summaries are post-processed by tools/summarise_profile.py
 # into profiles/.  Counter passes are kept apart from --kernel-trace/--stats as the pool requires.
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 shift || true
 BENCH_ARGS=${*:---steps 1000 --warmup 200 --no-cpu-baseline --no-extras}
 OUT=$PWD/gpurun_out/prof_$TAG

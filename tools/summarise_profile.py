@@ -14,7 +14,7 @@ import shutil
 import sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/prof_{tag}"
 key = sys.argv[3] if len(sys.argv) > 3 else None     # e.g. 4096x20x10_T200 -> profiles/traffic.json
 os.makedirs("profiles", exist_ok=True)
