@@ -1087,15 +1087,20 @@ Geometry plan_geometry(const uavtrack_config &cfg, int n_simd)
     static const int kLarge[] = {256, 128, 512, 64};
     static const int kSmall[] = {64, 128, 256, 512};
     // whole environments per workgroup: as many as there are lanes for, fewer when their tables would not fit
-    // the 64 KB of LDS a workgroup may have (few UAVs, many targets: N = 1, M = 70 fits 58 environments, not 64)
+    // the 64 KB of LDS a workgroup may have (few UAVs, many targets: N = 1, M = 70 fits 58 environments, not 64).
+    // The fused actor rollout adds 5 KB per wavefront behind the tables (actor.h): reserved here, so that every
+    // geometry this function returns can also run uavtrack_run_actor.
+    auto lds_need = [&](int wgs, int E) {
+        return lds_bytes_for(E, N, cfg.m_targets, cfg.dim == 3) + (size_t)(wgs / 64) * kActorLdsFloats * sizeof(float);
+    };
     auto envs_of = [&](int wgs) {
         int E = wgs / N;
-        while (E > 1 && lds_bytes_for(E, N, cfg.m_targets, cfg.dim == 3) > 64 * 1024) --E;
+        while (E > 1 && lds_need(wgs, E) > 64 * 1024) --E;
         return E;
     };
     auto feasible = [&](int wgs) {
         const int E = envs_of(wgs);
-        return E >= 1 && lds_bytes_for(E, N, cfg.m_targets, cfg.dim == 3) <= 64 * 1024;
+        return E >= 1 && lds_need(wgs, E) <= 64 * 1024;
     };
     auto util_of = [&](int wgs) {
         const int E = envs_of(wgs);

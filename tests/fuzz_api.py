@@ -37,7 +37,7 @@ def case(c, rng):
         B = max(1, 6000 // N)
     box = float(rng.choice([150.0, 600.0, 2000.0]))
     mode = int(rng.choice([0, 1, 2]))                       # RAW, MEAN, PMI
-    H = int(rng.choice([64, 128]))
+    H = int(rng.choice([64, 128, 128, 32, 96, 100, 160]))     # (other widths are padded to the scorer's 32-column blocks)
     T = int(rng.choice([1, 2, 7, 13]))
     off = int(rng.choice([0, 5, 10 ** 10]))
     dim = int(rng.choice([2, 2, 2, 3]))
