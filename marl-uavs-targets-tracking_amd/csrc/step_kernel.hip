@@ -529,7 +529,9 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     // Per-lane constants of the step loop: this lane's own slots in both table copies, and (when the
     // workgroup has at least one lane per target, as in every benchmark shape) its target's slot.
     float *const own0 = reinterpret_cast<float *>(uenv + (i >> 1) * 6) + (i & 1);
-    const bool one_target_per_lane = E * M <= nthreads;
+    // (register-resident targets cost five registers: at 50 x 25 that is the difference between three and four waves per
+    // SIMD -- 16.6 vs 17.4 G agent-steps/s at 8192 envs in 3-D -- so the larger shapes keep the LDS read-modify-write)
+    const bool one_target_per_lane = (LONE || (N_ > 0 && N_ <= 20)) && E * M <= nthreads;
     const bool my_target = tid < envs_here * M;
     float *tgt = reinterpret_cast<float *>(ttab);
     float ttx = 0, tty = 0, ttc = 1, tts = 0, tth = 0;   // the lane's own target, resident across the T steps
