@@ -231,6 +231,7 @@ int uavtrack_create(const uavtrack_config *cfg, uavtrack_env **out)
         return fail("uavtrack_create: dp=%g and dc=%g are too far apart for the fp32 range tests", cfg->dp, cfg->dc);
     }
     env->geo = plan_geometry(*cfg, prop.multiProcessorCount * 4);
+    env->n_cus = prop.multiProcessorCount;
     if (env->geo.wgs == 0) {
         delete env;
         return fail("uavtrack_create: no workgroup geometry for n_uav=%d", cfg->n_uav);
@@ -359,11 +360,12 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
     // and biases are zero (relu(0) = 0 adds nothing to any sum), so every hidden_dim runs on the same kernels.
     const int hp = pmi_padded_hidden(hidden);
     const size_t HP = (size_t)hp, n_dev = 12 * HP + 3 * HP + 3 * HP * HP + HP + HP + 1;
+    const size_t x6_off = (n_dev + 3) & ~(size_t)3, x6_len = pmi_x6_floats(hp);     // the bf16 planes, 16-B aligned
     if (env->pmi.n_floats != n_dev) {
         HIP_TRY(hipStreamSynchronize(st));
         if (env->pmi.blob) (void)hipFree(env->pmi.blob);
         env->pmi = PmiWeights();
-        HIP_TRY(dmalloc(&env->pmi.blob, n_dev));
+        HIP_TRY(dmalloc(&env->pmi.blob, x6_off + x6_len));
     }
     {   // fc1 goes up in the scorer's register order; the copy has completed before `packed` dies
         std::vector<float> padded(n_dev, 0.0f), packed(n_dev);
@@ -386,8 +388,14 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
         rows(1, 1, 1);                            // b2
         pack_pmi_blob(padded.data(), packed.data(), hp);
         HIP_TRY(hipMemcpyAsync(env->pmi.blob, packed.data(), n_dev * 4, hipMemcpyHostToDevice, st));
+        std::vector<uint16_t> planes(x6_len * 2);
+        if (x6_len) {
+            pack_pmi_x6(padded.data(), planes.data(), hp);
+            HIP_TRY(hipMemcpyAsync(env->pmi.blob + x6_off, planes.data(), x6_len * 4, hipMemcpyHostToDevice, st));
+        }
         HIP_TRY(hipStreamSynchronize(st));
     }
+    env->pmi.x6 = x6_len ? env->pmi.blob + x6_off : nullptr;
     env->pmi.hidden = hp;
     env->pmi.n_floats = n_dev;
     if (ensure_pmi_scratch(env, 1, st)) return 1;

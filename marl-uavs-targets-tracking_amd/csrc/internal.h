@@ -105,7 +105,8 @@ __host__ __device__ inline int nbrec_mask_words(int N) { return N <= 64 ? 2 : (N
 __host__ __device__ inline int nbrec_words(int N) { return nbrec_mask_words(N) + 2; }
 
 struct PmiWeights {
-    float *blob = nullptr;   // device, folded layout of uavtrack_set_pmi_weights
+    float *blob = nullptr;   // device, folded layout of uavtrack_set_pmi_weights; behind it the bf16 planes of fc1
+    const void *x6 = nullptr; // -> into blob: fc1 as three bf16 planes in MFMA operand order (pack_pmi_x6), or null
     int32_t hidden = 0;
     size_t n_floats = 0;
 };
@@ -128,6 +129,7 @@ struct uavtrack_env {
     uavtrack::StateBlock state;  // pointers into the slab (host-side view)
     uavtrack::Geometry geo;
     uavtrack::PmiWeights pmi;
+    int32_t n_cus = 0;           // compute units of the device (grid of the persistent scorer)
     float *actor_w = nullptr;    // device blob of uavtrack_set_actor_weights (actor.h layout)
     int32_t actor_hidden = 0;
     // MAAC-R scratch for `pmi_steps_cap` steps of deferred scoring (rewards never feed back into the
@@ -157,6 +159,10 @@ size_t rollout_lds_bytes(const uavtrack_env *env, int policy);   // dynamic LDS 
 constexpr int kPmiMaxHidden = 256;                  // widest PMINetwork hidden layer the scorer is instantiated for
 inline int pmi_padded_hidden(int hidden) { return (hidden + 31) / 32 * 32; }   // the scorer's column-block granule
 void pack_pmi_blob(const float *abi_blob, float *device_order, int hidden);
+constexpr int kPmiX6MaxHidden = 128;                // widest layer whose three bf16 planes stay register-resident (4 waves, one per SIMD)
+constexpr int kPmiX6MinHidden = 64;                 // (narrower layers have fewer k-steps than the producer has pairs to hide)
+inline size_t pmi_x6_floats(int hp) { return hp >= kPmiX6MinHidden && hp <= kPmiX6MaxHidden ? (size_t)3 * hp * hp * 3 / 2 : 0; }   // 3 planes x 2 B
+void pack_pmi_x6(const float *abi_blob, uint16_t *planes, int hidden);
 hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream_t stream);
 hipError_t launch_pmi_finalize(const uavtrack_env *env, int steps, float *reward, hipStream_t stream);
 hipError_t launch_ep_sums(const uavtrack_env *env, int steps, const float *reward, const float *terms,

@@ -26,6 +26,10 @@
 
 #include "internal.h"
 
+#include <cstdlib>
+#include <cstring>
+#include <utility>
+
 namespace uavtrack {
 
 namespace {
@@ -54,6 +58,7 @@ __device__ __forceinline__ float half_wave_sum(float v)
 
 struct PmiParams {
     const float *blob;       // folded weights, layout of uavtrack_set_pmi_weights
+    const void *x6;          // fc1 as three bf16 planes in MFMA B-operand order (pack_pmi_x6)
     const float *obs;        // [S][B][N][12] local states of the chunk's steps
     const uint2 *pairs;      // {flat [step][b][i] index of i within the chunk, j}
     const unsigned *pair_count;
@@ -235,6 +240,310 @@ __global__ void __launch_bounds__(H * 2, 2) pmi_score_kernel(const PmiParams q)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// pmi_score_x6_kernel<H>: the same scorer with the 3H x H layer on the BF16 matrix cores at fp32 accuracy.
+// gfx950 has no reduced-precision-but-wide fp32 MFMA (no xf32); its fp32-input MFMA runs at 1/16 of the bf16 rate.
+// An fp32 value is exactly the sum of three bf16 values (8 + 8 + 8 significant bits, split by truncation:
+// x = hi + mid + lo with hi = x & 0xFFFF0000, mid likewise of the exact remainder x - hi, ...), so
+//     x * w = xh*wh + (xh*wm + xm*wh) + (xh*wl + xl*wh + xm*wm) + O(2^-24 |x w|)
+// -- six bf16 MFMAs (v_mfma_f32_32x32x16_bf16: products exact, fp32 accumulate) replace eight fp32 ones of the same
+// tile at 1/16 the cycles each: 2.67x the fp32 matrix rate, with an error below that of an fp32 fmaf chain
+// (3.7e-6 against 1.1e-5 max over 384-term sums of O(1) data; tools/x6_accuracy.py).  Operands cannot overflow or
+// lose range: bf16 has fp32's exponent.
+//
+// Weight-stationary as above, but the three planes of a wavefront's 3H x 32 slice are 2.25 H registers (288 at
+// H = 128): one workgroup per CU, one wavefront per SIMD, 512 registers per lane (the planes are MFMA-only operands
+// and live in the accumulation-register half of the file).  The branch layers produce two adjacent k per thread,
+// split them on the VALU (v_and / v_sub / v_perm: 5.5 instructions per activation) and write the three planes of
+// the 32 x 3H activation tile to LDS in A-operand order, rows padded to a 16-byte-odd pitch (conflict-free
+// ds_read_b128 fragments).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+// Workgroup barrier that orders LDS traffic only (outstanding global loads stay in flight; the compiler still waits for
+// them where their registers are first used).
+#define UAVTRACK_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(<N - 1>).  (The staged main loop below indexes register
+// arrays and picks pieces of work by loop position; `#pragma unroll` leaves inner loops whose bounds depend on an outer
+// induction variable rolled, and the arrays then land in scratch.)
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F &&f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// the bf16 (truncated) parts of a float pair packed as (low half: .x, high half: .y); the pair becomes the exact remainders
+__device__ __forceinline__ unsigned split_pack(v2f &v)
+{
+    const unsigned ua = __float_as_uint(v.x), ub = __float_as_uint(v.y);
+    const unsigned packed = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+    v -= (v2f){__uint_as_float(ua & 0xFFFF0000u), __uint_as_float(ub & 0xFFFF0000u)};
+    return packed;
+}
+// (w.x, w.y) * x + (c.x, c.y): one v_pk_fma_f32
+__device__ __forceinline__ v2f pk_fma2(v2f w, float x, v2f c)
+{
+#if __has_builtin(__builtin_elementwise_fma)
+    return __builtin_elementwise_fma(w, (v2f){x, x}, c);
+#else
+    return (v2f){fmaf(w.x, x, c.x), fmaf(w.y, x, c.y)};
+#endif
+}
+template <int H>
+__global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams q)
+{
+    constexpr int K = 3 * H;             // fc1 input width
+    constexpr int KS = K / 16;           // MFMA k-steps (32x32x16)
+    constexpr int PITCH = K * 2 + 16;    // bytes per activation row of one plane
+    constexpr int PLANE = 32 * PITCH;    // bytes per plane of a tile
+    constexpr int NW = H / 32;           // wavefronts = column blocks
+    constexpr int NT = NW * 64;          // threads = 2 H
+    constexpr int OP = H / 2;            // adjacent-output pairs per branch
+    constexpr int PG = NT / OP;          // pair groups (4)
+    constexpr int PPT = 32 / PG;         // pairs per thread in the branch layers (8)
+    static_assert(KS >= PPT, "every produced pair needs at least one k-step to hide behind");
+
+    __shared__ float4 lds4[(2 * 3 * PLANE + (2 * 32 * 12 + 2 * NW * 32) * 4) / 16 + 2];
+    unsigned char *aplanes = reinterpret_cast<unsigned char *>(lds4);               // [2 tiles][3 planes][32 pairs][PITCH]
+    float *xs = reinterpret_cast<float *>(aplanes + 2 * 3 * PLANE);                // [2 tiles][32 pairs][12]
+    float *part = xs + 2 * 32 * 12;                                                // [2 tiles][NW][32]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int col = w * 32 + (lane & 31);
+    const int kh = lane >> 5;
+
+    // ---- stationary operands: the three bf16 planes of fc1's slice, in MFMA B-operand order (pack_pmi_x6)
+    const float *W1 = q.blob + 15 * H;
+    const float *b1 = W1 + (size_t)K * H;
+    const float *w2 = b1 + H;
+    const float b2 = w2[H];
+    u32x4 Bh[KS], Bm[KS], Bl[KS];
+    {
+        const u32x4 *bp = reinterpret_cast<const u32x4 *>(q.x6) + (size_t)w * 3 * KS * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            Bh[s] = bp[(0 * KS + s) * 64];
+            Bm[s] = bp[(1 * KS + s) * 64];
+            Bl[s] = bp[(2 * KS + s) * 64];
+        }
+    }
+    const float bias1 = b1[col], wout = w2[col];
+
+    // Branch layers (PMINet.py:50-55): thread (o2, pg) owns outputs 2 o2 and 2 o2 + 1 of each of the three branches
+    // for PPT of the tile's 32 pairs; its 30 folded weights and 6 biases stay in registers as (even, odd) pairs, so
+    // one packed instruction serves both outputs.
+    const int o2 = tid % OP, pg = tid / OP;
+    v2f wc[5], wo[4], wb[3], bc, bo, bb;
+    {
+        const int o = 2 * o2;
+#pragma unroll
+        for (int v = 0; v < 5; ++v) wc[v] = (v2f){q.blob[v * H + o], q.blob[v * H + o + 1]};
+        bc = (v2f){q.blob[5 * H + o], q.blob[5 * H + o + 1]};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) wo[v] = (v2f){q.blob[6 * H + v * H + o], q.blob[6 * H + v * H + o + 1]};
+        bo = (v2f){q.blob[10 * H + o], q.blob[10 * H + o + 1]};
+#pragma unroll
+        for (int v = 0; v < 3; ++v) wb[v] = (v2f){q.blob[11 * H + v * H + o], q.blob[11 * H + v * H + o + 1]};
+        bb = (v2f){q.blob[14 * H + o], q.blob[14 * H + o + 1]};
+    }
+    // where this thread's outputs live in a plane's row: concat order comm | obs | boundary_state (PMINet.py:58)
+    const int arow0 = (pg * PPT) * PITCH + 4 * o2;
+    const int afrag0 = (lane & 31) * PITCH + kh * 16;
+
+    const unsigned npairs = *q.pair_count;
+    const unsigned ntiles = (npairs + 31) >> 5;
+    const unsigned G = gridDim.x;
+    if (blockIdx.x == 0 && tid == 0) *q.pair_total += npairs;      // accounting only (one writer)
+
+    // Inputs of a tile, by the first 32 threads: pair record -> the two observations -> x = la_i * la_j (uav.py:281).
+    // Two dependent trips to memory, so the main loop runs them as a pipeline one tile deep each: a record is
+    // requested three tiles ahead, its observations two tiles ahead, and neither request is ever waited for in the
+    // iteration that issued it (a wait here would hold every wavefront at the tile's barrier).
+    auto load_rec = [&](unsigned tile, uint2 &pr, bool &ok) {
+        const unsigned pi = tile * 32 + tid;
+        ok = tid < 32 && tile < ntiles && pi < npairs;
+        pr = make_uint2(0, 0);
+        if (ok) pr = q.pairs[pi];
+    };
+    auto load_obs = [&](uint2 pr, bool ok, float4 (&a)[3], float4 (&b)[3]) {
+        a[0] = a[1] = a[2] = b[0] = b[1] = b[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+            const unsigned gi = pr.x, gj = (pr.x / q.N) * q.N + pr.y;
+            const float4 *oi = reinterpret_cast<const float4 *>(q.obs + (size_t)gi * 12);
+            const float4 *oj = reinterpret_cast<const float4 *>(q.obs + (size_t)gj * 12);
+#pragma unroll
+            for (int v = 0; v < 3; ++v) { a[v] = oi[v]; b[v] = oj[v]; }
+        }
+    };
+    auto stash = [&](int buf, const float4 (&a)[3], const float4 (&b)[3]) {
+        if (tid < 32) {
+            float4 *dst = reinterpret_cast<float4 *>(xs + buf * 32 * 12 + tid * 12);
+#pragma unroll
+            for (int v = 0; v < 3; ++v) dst[v] = make_float4(a[v].x * b[v].x, a[v].y * b[v].y, a[v].z * b[v].z, a[v].w * b[v].w);
+        }
+    };
+    // One pair of the branch layers -- 12 packed FMAs, ReLU, three-way split, nine 4-byte LDS writes -- cut into
+    // kMicro pieces so that the main loop can place a piece behind each MFMA (see there).  `xn` holds the inputs of
+    // the pair after this one: requested by piece kMicro - 4, consumed from piece 1 of the next pair on.
+    constexpr int kMicro = 18;
+    struct Prod { float4 xa, xb, xc, na, nb, nc; v2f c, ob, bs; };
+    auto load_x = [&](int xbuf, int pp, float4 &xa, float4 &xb, float4 &xc) {
+        const float4 *xp = reinterpret_cast<const float4 *>(xs + xbuf * 32 * 12 + (pg * PPT + pp) * 12);
+        xa = xp[0]; xb = xp[1]; xc = xp[2];
+    };
+    auto micro = [&](Prod &P, auto opc, int xbuf, int abuf, int pp) {
+        constexpr int op = decltype(opc)::value;
+        unsigned char *dst = aplanes + abuf * 3 * PLANE + arow0 + pp * PITCH;
+        if constexpr (op == 0) { P.xa = P.na; P.xb = P.nb; P.xc = P.nc; }
+        else if constexpr (op == 1) { P.c = pk_fma2(wc[0], P.xa.x, bc); P.c = pk_fma2(wc[1], P.xa.y, P.c); }
+        else if constexpr (op == 2) { P.c = pk_fma2(wc[2], P.xa.z, P.c); P.c = pk_fma2(wc[3], P.xa.w, P.c); }
+        else if constexpr (op == 3) { P.c = pk_fma2(wc[4], P.xb.x, P.c); P.ob = pk_fma2(wo[0], P.xb.y, bo); }
+        else if constexpr (op == 4) { P.ob = pk_fma2(wo[1], P.xb.z, P.ob); P.ob = pk_fma2(wo[2], P.xb.w, P.ob); }
+        else if constexpr (op == 5) { P.ob = pk_fma2(wo[3], P.xc.x, P.ob); P.bs = pk_fma2(wb[0], P.xc.y, bb); }
+        else if constexpr (op == 6) { P.bs = pk_fma2(wb[1], P.xc.z, P.bs); P.bs = pk_fma2(wb[2], P.xc.w, P.bs); }
+        else if constexpr (op == 7) { P.c = (v2f){fmaxf(P.c.x, 0.0f), fmaxf(P.c.y, 0.0f)}; P.ob = (v2f){fmaxf(P.ob.x, 0.0f), fmaxf(P.ob.y, 0.0f)}; }
+        else if constexpr (op == 8) { P.bs = (v2f){fmaxf(P.bs.x, 0.0f), fmaxf(P.bs.y, 0.0f)}; }
+        else if constexpr (op == 9)  *reinterpret_cast<unsigned *>(dst + 0 * PLANE) = split_pack(P.c);            // plane 0: hi
+        else if constexpr (op == 10) *reinterpret_cast<unsigned *>(dst + 0 * PLANE + 2 * H) = split_pack(P.ob);
+        else if constexpr (op == 11) *reinterpret_cast<unsigned *>(dst + 0 * PLANE + 4 * H) = split_pack(P.bs);
+        else if constexpr (op == 12) *reinterpret_cast<unsigned *>(dst + 1 * PLANE) = split_pack(P.c);            // plane 1: mid
+        else if constexpr (op == 13) *reinterpret_cast<unsigned *>(dst + 1 * PLANE + 2 * H) = split_pack(P.ob);
+        else if constexpr (op == 14) {
+            *reinterpret_cast<unsigned *>(dst + 1 * PLANE + 4 * H) = split_pack(P.bs);
+            if (pp + 1 < PPT) load_x(xbuf, pp + 1, P.na, P.nb, P.nc);
+        }
+        else if constexpr (op == 15) *reinterpret_cast<unsigned *>(dst + 2 * PLANE) = split_pack(P.c);            // plane 2: lo
+        else if constexpr (op == 16) *reinterpret_cast<unsigned *>(dst + 2 * PLANE + 2 * H) = split_pack(P.ob);
+        else *reinterpret_cast<unsigned *>(dst + 2 * PLANE + 4 * H) = split_pack(P.bs);
+    };
+    auto produce_pair = [&](Prod &P, int xbuf, int abuf, int pp) {       // all of it at once (prologue)
+        static_for<kMicro>([&](auto opc) { micro(P, opc, xbuf, abuf, pp); });
+    };
+
+    // ---- prologue: the first tile's activation planes; the second tile's inputs in xs[1]; the third's observations
+    //      and the fourth's pair record in flight
+    uint2 rec_n;
+    bool rec_ok;
+    float4 oa[3], ob[3];
+    {
+        load_rec(blockIdx.x, rec_n, rec_ok);
+        load_obs(rec_n, rec_ok, oa, ob);
+        stash(0, oa, ob);
+        load_rec(blockIdx.x + G, rec_n, rec_ok);
+        load_obs(rec_n, rec_ok, oa, ob);
+        __syncthreads();
+        Prod P0;
+        load_x(0, 0, P0.na, P0.nb, P0.nc);
+#pragma unroll 2
+        for (int pp = 0; pp < PPT; ++pp) produce_pair(P0, 0, 0, pp);
+        stash(1, oa, ob);
+        load_rec(blockIdx.x + 2 * G, rec_n, rec_ok);
+        load_obs(rec_n, rec_ok, oa, ob);
+        load_rec(blockIdx.x + 3 * G, rec_n, rec_ok);
+        __syncthreads();
+    }
+
+    // ReLU, fc2 (PMINet.py:60-61) of a finished tile, row r of this wavefront's 16: sum over the block's 32 columns in
+    // a fixed butterfly order (bitwise reproducible).  Three pieces, so the main loop can hide them too.
+    auto epi_piece = [&](const f32x16 &a, float &ev, auto ec, float *pc) {
+        constexpr int e = decltype(ec)::value, r = e / 3;
+        if constexpr (e % 3 == 0) { ev = fmaxf(a[r], 0.0f) * wout; ev = dpp_add<0xB1>(ev); }
+        else if constexpr (e % 3 == 1) { ev = dpp_add<0x4E>(ev); ev = dpp_add<0x141>(ev); }
+        else {
+            ev = dpp_add<0x140>(ev); ev = dpp_add<0x142, 0xa>(ev);
+            // C/D layout of 32x32 MFMA: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+            if ((lane & 31) == 16) pc[w * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh] = ev;
+        }
+    };
+    auto final_sum = [&](unsigned tile, const float *pc) {      // over the column blocks, in order
+        if (tid < 32 && tile * 32 + tid < npairs) {
+            float sc = b2;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) sc += pc[ww * 32 + tid];
+            q.scores[tile * 32 + tid] = sc;                     // the pair's own slot: s_ij = s_ji is stored once
+        }
+    };
+
+    int cur = 0;
+    bool have_prev = false;
+    f32x16 accp;                             // the previous tile's accumulators: their epilogue runs under this tile's MFMAs
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accp[r] = 0.0f;
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += G) {
+        // ---- fc1 (+ folded bn1) of this tile: [32 pairs x 3H] x [3H x 32 cols], six bf16 MFMAs per k-step (small
+        //      terms first), interleaved in program order with the branch layers of the NEXT tile: a wavefront issues
+        //      in order and an MFMA holds its SIMD's issue for 8 of its 32 cycles, so the VALU / LDS instructions
+        //      placed between two MFMAs of the one accumulation chain run in the shadow of the first
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bias1;
+        const unsigned char *afrag = aplanes + cur * 3 * PLANE + afrag0;
+        auto load_a = [&](int s, u32x4 &h, u32x4 &m, u32x4 &l) {
+            h = *reinterpret_cast<const u32x4 *>(afrag + 0 * PLANE + s * 32);
+            m = *reinterpret_cast<const u32x4 *>(afrag + 1 * PLANE + s * 32);
+            l = *reinterpret_cast<const u32x4 *>(afrag + 2 * PLANE + s * 32);
+        };
+        Prod P;
+        load_x(cur ^ 1, 0, P.na, P.nb, P.nc);
+        float ev = 0.0f;
+        float *pcp = part + (cur ^ 1) * NW * 32;        // the previous tile's partial scores
+        u32x4 fh, fm, fl, gh, gm, gl;            // this k-step's fragments, the next one's
+        load_a(0, fh, fm, fl);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<KS>([&](auto sc) {
+            // k-step s belongs to pair pp's share; its six MFMA slots carry the micro-ops [lo, hi) of that pair
+            constexpr int s = decltype(sc)::value;
+            constexpr int pp = s * PPT / KS;
+            constexpr int s0 = (pp * KS + PPT - 1) / PPT, s1 = ((pp + 1) * KS + PPT - 1) / PPT;   // first k-step of pp, of pp + 1
+            constexpr int nslot = 6 * (s1 - s0);
+            static_for<6>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int slot = 6 * (s - s0) + t;
+                constexpr int lo = slot * kMicro / nslot, hi = (slot + 1) * kMicro / nslot;
+                const bf16x8 a = as_bf16x8(t == 1 ? fl : (t == 2 || t == 4) ? fm : fh);
+                const bf16x8 bq = as_bf16x8(t == 0 ? Bl[s] : (t == 2 || t == 3) ? Bm[s] : Bh[s]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc, 0, 0, 0);
+                if constexpr (t == 0 && s + 1 < KS) load_a(s + 1, gh, gm, gl);
+                static_for<kMicro>([&](auto opc) {
+                    if constexpr (decltype(opc)::value >= lo && decltype(opc)::value < hi) micro(P, opc, cur ^ 1, cur ^ 1, pp);
+                });
+                // the previous tile's epilogue: 48 pieces over the 6 KS slots
+                constexpr int gslot = 6 * s + t, elo = gslot * 48 / (6 * KS), ehi = (gslot + 1) * 48 / (6 * KS);
+                static_for<48>([&](auto ec) {
+                    if constexpr (decltype(ec)::value >= elo && decltype(ec)::value < ehi) epi_piece(accp, ev, ec, pcp);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            fh = gh; fm = gm; fl = gl;
+        });
+
+        // xs[cur] fed this tile's branch layers during the previous iteration: free for the tile after the next
+        stash(cur, oa, ob);                                   // x of tile + 2 G (observations requested an iteration ago)
+        load_obs(rec_n, rec_ok, oa, ob);                      // tile + 3 G (record requested an iteration ago)
+        load_rec(tile + 4 * G, rec_n, rec_ok);
+        // next tile's planes, the previous tile's partials and xs[cur] are complete.  An LDS-only barrier: __syncthreads()
+        // also drains the vector-memory counter, i.e. it would wait out the two requests the first wavefront has just
+        // made -- a full trip to memory per tile, with every other wavefront parked at the barrier meanwhile.
+        UAVTRACK_LDS_BARRIER();
+        if (have_prev) final_sum(tile - G, pcp);
+        accp = acc;
+        have_prev = true;
+        cur ^= 1;
+    }
+    if (have_prev) {                         // the last tile's epilogue has nothing left to hide behind
+        float ev = 0.0f;
+        float *pcp = part + (cur ^ 1) * NW * 32;
+        static_for<48>([&](auto ec) { epi_piece(accp, ev, ec, pcp); });
+        __syncthreads();
+        // (the last tile of this workgroup: blockIdx.x + G * (its tile count - 1))
+        const unsigned last = blockIdx.x + ((ntiles - 1 - blockIdx.x) / G) * G;
+        final_sum(last, pcp);
+    }
+}
+
 struct MixParams {
     const uint32_t *nbrec;       // [S][B][N][W + 2] neighbour records of the chunk's S steps
     const float *scores;         // one per pair
@@ -382,10 +691,35 @@ void pack_pmi_blob(const float *abi_blob, float *device_order, int H)
                         W1[(size_t)(2 * (4 * t4 + q) + (l >> 5)) * H + w * 32 + (l & 31)];
 }
 
+// fc1 as three bf16 planes (x = hi + mid + lo by truncation, exact) in the B-operand order of
+// v_mfma_f32_32x32x16_bf16: per column block w, plane p, k-step s and lane l the eight values
+// k = 16 s + 8 (l >> 5) + j, j = 0..7, of column 32 w + (l & 31).
+void pack_pmi_x6(const float *abi_blob, uint16_t *planes, int H)
+{
+    const int K = 3 * H, KS = K / 16, NW = H / 32;
+    const float *W1 = abi_blob + (size_t)15 * H;
+    for (int w = 0; w < NW; ++w)
+        for (int s = 0; s < KS; ++s)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    float v = W1[(size_t)(16 * s + 8 * (l >> 5) + j) * H + w * 32 + (l & 31)];
+                    for (int p = 0; p < 3; ++p) {
+                        uint32_t u;
+                        memcpy(&u, &v, 4);
+                        u &= 0xFFFF0000u;
+                        float hi;
+                        memcpy(&hi, &u, 4);
+                        planes[((((size_t)w * 3 + p) * KS + s) * 64 + l) * 8 + j] = (uint16_t)(u >> 16);
+                        v -= hi;                     // exact: the remainder has at most 16 significant bits left
+                    }
+                }
+}
+
 hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream_t stream)
 {
     PmiParams q;
     q.blob = env->pmi.blob;
+    q.x6 = env->pmi.x6;
     q.obs = obs;
     q.pairs = env->pairs;
     q.pair_count = env->pair_count;
@@ -398,6 +732,19 @@ hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream
     // Built for every multiple of 32 up to kPmiMaxHidden (uavtrack_set_pmi_weights pads other widths); tuned at the
     // reference's two: 128 (configs/MAAC-R.yaml) and 64 (the class default).  Past 128 the stationary slice no longer
     // fits 256 registers and part of it lives in scratch: correct, slower.
+    // Widths up to kPmiX6MaxHidden run the layer as six bf16 MFMAs per k-step (pmi_score_x6_kernel): one persistent
+    // workgroup per CU.  UAVTRACK_PMI_FP32=1 keeps the fp32-MFMA kernel (A/B measurements, and the wider layers).
+    static const bool force_fp32 = [] { const char *s = getenv("UAVTRACK_PMI_FP32"); return s && atoi(s) != 0; }();
+    if (q.x6 && !force_fp32) {
+        const int grid6 = env->n_cus > 0 ? env->n_cus : 256;
+        switch (env->pmi.hidden) {
+#define UAVTRACK_PMI_CASE(HH) case HH: hipLaunchKernelGGL(pmi_score_x6_kernel<HH>, dim3(grid6), dim3(2 * HH), 0, stream, q); break;
+            UAVTRACK_PMI_CASE(64) UAVTRACK_PMI_CASE(96) UAVTRACK_PMI_CASE(128)
+#undef UAVTRACK_PMI_CASE
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     const int grid = 512;
     switch (env->pmi.hidden) {
 #define UAVTRACK_PMI_CASE(HH) case HH: hipLaunchKernelGGL(pmi_score_kernel<HH>, dim3(grid), dim3(2 * HH), 0, stream, q); break;
