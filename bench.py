@@ -613,16 +613,35 @@ def worker(args):
             flop_pair = 2.0 * (12 * H + 3 * H * H + H)               # 101 632 at H = 128
             tf = roof["pmi_pairs"] * flop_pair / (sum(roof["ms"]) * 1e-3) / 1e12
             line["roofline_hbm_all_kernels"] = line["roofline"]
-            line["roofline"] = {
-                "bound": "mfma", "kernel": "pmi_score_kernel", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s",
-                "frac": tf / 157.3, "traffic": None,
-                "flop_per_pair": flop_pair, "pairs_scored": roof["pmi_pairs"],
+            hp = (H + 31) // 32 * 32
+            x6 = 64 <= hp <= 128 and os.environ.get("UAVTRACK_PMI_FP32", "0") in ("", "0")
+            secs = sum(roof["ms"]) * 1e-3
+            common = {
+                "traffic": None, "flop_per_pair": flop_pair, "pairs_scored": roof["pmi_pairs"],
                 "pairs_per_agent_step": roof["pmi_pairs"] / (units_per_launch * roof["launches"]),
                 "steps_per_launch": roof["T"], "launches_timed": roof["launches"], "avg_launch_ms": roof["avg_ms"],
                 "timing": "HIP events around every uavtrack_step_many call of the fixed leg (all kernels of each chunk: a "
                           "lower bound for the scorer alone; the per-kernel split is in profiles/)",
-                "peak_note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak = fp32 vector peak, MI355X_MICROARCH.md",
+                "fp32_equivalent_tflops": tf, "fp32_equivalent_over_fp32_mfma_peak": tf / 157.3,
             }
+            if x6:
+                # pmi_score_x6_kernel: the 3H x H layer as SIX bf16 MFMAs per fp32 product (three-way bf16 split, fp32
+                # accuracy).  The roof that bounds it is the bf16 matrix rate; `achieved` counts the bf16 flops the
+                # matrix cores really execute (6 x 2 x 3H x H per pair), not the fp32-equivalent work.
+                executed = roof["pmi_pairs"] * 6.0 * 2.0 * 3 * hp * hp / secs / 1e12
+                line["roofline"] = {
+                    "bound": "mfma", "kernel": "pmi_score_x6_kernel", "achieved": executed, "peak": 2500.0, "unit": "TFLOP/s",
+                    "frac": executed / 2500.0, **common,
+                    "peak_note": "bf16 MFMA dense peak (~2.5 PFLOP/s, MI355X_MICROARCH.md); executed flops = 6 bf16 MFMAs per "
+                                 "fp32 product; fp32_equivalent_* restate the same time as plain fp32 work against the 157.3 "
+                                 "TFLOP/s fp32-MFMA peak the round-1 scorer was bounded by",
+                }
+            else:
+                line["roofline"] = {
+                    "bound": "mfma", "kernel": "pmi_score_kernel", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s",
+                    "frac": tf / 157.3, **common,
+                    "peak_note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak = fp32 vector peak, MI355X_MICROARCH.md",
+                }
         if args.policy == "actor":
             # the actor adds 2*(12*H + H*16*tiles) fp32 MFMA flops per agent-step (actions padded to 16-row tiles: 1 in 2-D, 3 in 3-D)
             Hp = (args.actor_hidden + 15) // 16 * 16

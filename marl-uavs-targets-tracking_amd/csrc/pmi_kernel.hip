@@ -273,23 +273,33 @@ __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>
 template <int N, class F>
 __device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
-// the bf16 (truncated) parts of a float pair packed as (low half: .x, high half: .y); the pair becomes the exact remainders
-__device__ __forceinline__ unsigned split_pack(v2f &v)
+// Pieces of the three-way split of a float pair: its bf16 (truncated) parts as floats, those parts packed as
+// (low half: .x, high half: .y), and the exact remainder v - hi.
+__device__ __forceinline__ v2f bf16_part(v2f v)
 {
-    const unsigned ua = __float_as_uint(v.x), ub = __float_as_uint(v.y);
-    const unsigned packed = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
-    v -= (v2f){__uint_as_float(ua & 0xFFFF0000u), __uint_as_float(ub & 0xFFFF0000u)};
-    return packed;
+    return (v2f){__uint_as_float(__float_as_uint(v.x) & 0xFFFF0000u), __uint_as_float(__float_as_uint(v.y) & 0xFFFF0000u)};
 }
-// (w.x, w.y) * x + (c.x, c.y): one v_pk_fma_f32
-__device__ __forceinline__ v2f pk_fma2(v2f w, float x, v2f c)
+__device__ __forceinline__ unsigned pack_hi16(v2f v)
 {
-#if __has_builtin(__builtin_elementwise_fma)
+    return __builtin_amdgcn_perm(__float_as_uint(v.y), __float_as_uint(v.x), 0x07060302u);
+}
+__device__ __forceinline__ v2f pk_sub(v2f v, v2f hi)
+{
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(v), "v"(hi));
+    return d;
+}
+// ReLU of a pair
+__device__ __forceinline__ v2f relu2(v2f v) { return (v2f){fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f)}; }
+// (w.x, w.y) * x + (c.x, c.y), x being the low (HI = false) or high half of the register pair `xx`: one v_pk_fma_f32
+// whose op_sel does the broadcast
+template <bool HI>
+__device__ __forceinline__ v2f pk_fma_b(v2f w, v2f xx, v2f c)
+{
+    const float x = HI ? xx.y : xx.x;
     return __builtin_elementwise_fma(w, (v2f){x, x}, c);
-#else
-    return (v2f){fmaf(w.x, x, c.x), fmaf(w.y, x, c.y)};
-#endif
 }
+
 template <int H>
 __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams q)
 {
@@ -304,10 +314,11 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
     constexpr int PPT = 32 / PG;         // pairs per thread in the branch layers (8)
     static_assert(KS >= PPT, "every produced pair needs at least one k-step to hide behind");
 
-    __shared__ float4 lds4[(2 * 3 * PLANE + (2 * 32 * 12 + 2 * NW * 32) * 4) / 16 + 2];
+    __shared__ float4 lds4[(2 * 3 * PLANE + (2 * 32 * 12 + 2 * NW * 32 + NW * 96) * 4) / 16 + 2];
     unsigned char *aplanes = reinterpret_cast<unsigned char *>(lds4);               // [2 tiles][3 planes][32 pairs][PITCH]
     float *xs = reinterpret_cast<float *>(aplanes + 2 * 3 * PLANE);                // [2 tiles][32 pairs][12]
     float *part = xs + 2 * 32 * 12;                                                // [2 tiles][NW][32]
+    float *sink = part + 2 * NW * 32;                                              // [NW][96] where non-writer lanes' stores go
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -329,6 +340,10 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
             Bm[s] = bp[(1 * KS + s) * 64];
             Bl[s] = bp[(2 * KS + s) * 64];
         }
+        // hi and mid planes into the accumulation-register file for good (192 of its 256): the MFMAs read them from there
+        // directly -- left to itself the allocator parks them there too, but copies each fragment back before its use
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { asm volatile("" : "+a"(Bh[s])); asm volatile("" : "+a"(Bm[s])); }
     }
     const float bias1 = b1[col], wout = w2[col];
 
@@ -385,39 +400,39 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
             for (int v = 0; v < 3; ++v) dst[v] = make_float4(a[v].x * b[v].x, a[v].y * b[v].y, a[v].z * b[v].z, a[v].w * b[v].w);
         }
     };
-    // One pair of the branch layers -- 12 packed FMAs, ReLU, three-way split, nine 4-byte LDS writes -- cut into
-    // kMicro pieces so that the main loop can place a piece behind each MFMA (see there).  `xn` holds the inputs of
-    // the pair after this one: requested by piece kMicro - 4, consumed from piece 1 of the next pair on.
-    constexpr int kMicro = 18;
-    struct Prod { float4 xa, xb, xc, na, nb, nc; v2f c, ob, bs; };
-    auto load_x = [&](int xbuf, int pp, float4 &xa, float4 &xb, float4 &xc) {
+    // One pair of the branch layers -- 12 packed FMAs, ReLU, three-way split, nine 4-byte LDS writes -- as a list of
+    // kMicro atoms of one or two instructions, so that the main loop can deal them out evenly behind its MFMAs (see
+    // there).  The inputs of the next pair are requested by atom kLoadAtom, once this pair's FMAs have consumed theirs.
+    constexpr int kMicro = 37, kLoadAtom = 20;
+    struct Prod { float4 x[3]; v2f v[3], hi[3]; };      // inputs; the three branches' output pairs / remainders; their bf16 parts
+    auto load_x = [&](int xbuf, int pp, Prod &P) {
         const float4 *xp = reinterpret_cast<const float4 *>(xs + xbuf * 32 * 12 + (pg * PPT + pp) * 12);
-        xa = xp[0]; xb = xp[1]; xc = xp[2];
+        P.x[0] = xp[0]; P.x[1] = xp[1]; P.x[2] = xp[2];
     };
     auto micro = [&](Prod &P, auto opc, int xbuf, int abuf, int pp) {
         constexpr int op = decltype(opc)::value;
         unsigned char *dst = aplanes + abuf * 3 * PLANE + arow0 + pp * PITCH;
-        if constexpr (op == 0) { P.xa = P.na; P.xb = P.nb; P.xc = P.nc; }
-        else if constexpr (op == 1) { P.c = pk_fma2(wc[0], P.xa.x, bc); P.c = pk_fma2(wc[1], P.xa.y, P.c); }
-        else if constexpr (op == 2) { P.c = pk_fma2(wc[2], P.xa.z, P.c); P.c = pk_fma2(wc[3], P.xa.w, P.c); }
-        else if constexpr (op == 3) { P.c = pk_fma2(wc[4], P.xb.x, P.c); P.ob = pk_fma2(wo[0], P.xb.y, bo); }
-        else if constexpr (op == 4) { P.ob = pk_fma2(wo[1], P.xb.z, P.ob); P.ob = pk_fma2(wo[2], P.xb.w, P.ob); }
-        else if constexpr (op == 5) { P.ob = pk_fma2(wo[3], P.xc.x, P.ob); P.bs = pk_fma2(wb[0], P.xc.y, bb); }
-        else if constexpr (op == 6) { P.bs = pk_fma2(wb[1], P.xc.z, P.bs); P.bs = pk_fma2(wb[2], P.xc.w, P.bs); }
-        else if constexpr (op == 7) { P.c = (v2f){fmaxf(P.c.x, 0.0f), fmaxf(P.c.y, 0.0f)}; P.ob = (v2f){fmaxf(P.ob.x, 0.0f), fmaxf(P.ob.y, 0.0f)}; }
-        else if constexpr (op == 8) { P.bs = (v2f){fmaxf(P.bs.x, 0.0f), fmaxf(P.bs.y, 0.0f)}; }
-        else if constexpr (op == 9)  *reinterpret_cast<unsigned *>(dst + 0 * PLANE) = split_pack(P.c);            // plane 0: hi
-        else if constexpr (op == 10) *reinterpret_cast<unsigned *>(dst + 0 * PLANE + 2 * H) = split_pack(P.ob);
-        else if constexpr (op == 11) *reinterpret_cast<unsigned *>(dst + 0 * PLANE + 4 * H) = split_pack(P.bs);
-        else if constexpr (op == 12) *reinterpret_cast<unsigned *>(dst + 1 * PLANE) = split_pack(P.c);            // plane 1: mid
-        else if constexpr (op == 13) *reinterpret_cast<unsigned *>(dst + 1 * PLANE + 2 * H) = split_pack(P.ob);
-        else if constexpr (op == 14) {
-            *reinterpret_cast<unsigned *>(dst + 1 * PLANE + 4 * H) = split_pack(P.bs);
-            if (pp + 1 < PPT) load_x(xbuf, pp + 1, P.na, P.nb, P.nc);
+        if constexpr (op < 12) {
+            // FMA `op` of the 12: input i = op of x = (la_i * la_j)[0..11]; branch comm takes 0..4, obs 5..8, boundary 9..11
+            constexpr int br = op < 5 ? 0 : op < 9 ? 1 : 2, first = op == 0 || op == 5 || op == 9;
+            const float4 &f = P.x[op / 4];
+            const v2f xx = (op % 4) / 2 ? (v2f){f.z, f.w} : (v2f){f.x, f.y};
+            const v2f wgt = br == 0 ? wc[op] : br == 1 ? wo[op - 5] : wb[op - 9];
+            const v2f bias = br == 0 ? bc : br == 1 ? bo : bb;
+            P.v[br] = pk_fma_b<(op % 2) != 0>(wgt, xx, first ? bias : P.v[br]);
+        } else if constexpr (op < 15) {
+            P.v[op - 12] = relu2(P.v[op - 12]);
+        } else if constexpr (op < 33) {
+            // planes 0 (hi) and 1 (mid), branch by branch: bf16 parts, packed store, exact remainder
+            constexpr int q = op - 15, pl = q / 9, br = (q % 9) / 3, step = q % 3;
+            if constexpr (step == 0) P.hi[br] = bf16_part(P.v[br]);
+            else if constexpr (step == 1) *reinterpret_cast<unsigned *>(dst + pl * PLANE + br * 2 * H) = pack_hi16(P.v[br]);
+            else P.v[br] = pk_sub(P.v[br], P.hi[br]);
+        } else if constexpr (op < 36) {
+            constexpr int br = op - 33;     // plane 2 (lo): what is left, truncated
+            *reinterpret_cast<unsigned *>(dst + 2 * PLANE + br * 2 * H) = pack_hi16(P.v[br]);
         }
-        else if constexpr (op == 15) *reinterpret_cast<unsigned *>(dst + 2 * PLANE) = split_pack(P.c);            // plane 2: lo
-        else if constexpr (op == 16) *reinterpret_cast<unsigned *>(dst + 2 * PLANE + 2 * H) = split_pack(P.ob);
-        else *reinterpret_cast<unsigned *>(dst + 2 * PLANE + 4 * H) = split_pack(P.bs);
+        if constexpr (op == kLoadAtom) { if (pp + 1 < PPT) load_x(xbuf, pp + 1, P); }
     };
     auto produce_pair = [&](Prod &P, int xbuf, int abuf, int pp) {       // all of it at once (prologue)
         static_for<kMicro>([&](auto opc) { micro(P, opc, xbuf, abuf, pp); });
@@ -436,7 +451,7 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
         load_obs(rec_n, rec_ok, oa, ob);
         __syncthreads();
         Prod P0;
-        load_x(0, 0, P0.na, P0.nb, P0.nc);
+        load_x(0, 0, P0);
 #pragma unroll 2
         for (int pp = 0; pp < PPT; ++pp) produce_pair(P0, 0, 0, pp);
         stash(1, oa, ob);
@@ -454,9 +469,13 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
         else if constexpr (e % 3 == 1) { ev = dpp_add<0x4E>(ev); ev = dpp_add<0x141>(ev); }
         else {
             ev = dpp_add<0x140>(ev); ev = dpp_add<0x142, 0xa>(ev);
-            // C/D layout of 32x32 MFMA: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-            if ((lane & 31) == 16) pc[w * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh] = ev;
+            // C/D layout of 32x32 MFMA: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).  Every lane stores: `pc` is the
+            // writer lane's slot base and a private sink for the others (no exec-mask juggling between the MFMAs).
+            pc[(r & 3) + 8 * (r >> 2)] = ev;
         }
+    };
+    auto partial_base = [&](int buf) {
+        return (lane & 31) == 16 ? part + buf * NW * 32 + w * 32 + 4 * kh : sink + w * 96 + lane;
     };
     auto final_sum = [&](unsigned tile, const float *pc) {      // over the column blocks, in order
         if (tid < 32 && tile * 32 + tid < npairs) {
@@ -487,9 +506,9 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
             l = *reinterpret_cast<const u32x4 *>(afrag + 2 * PLANE + s * 32);
         };
         Prod P;
-        load_x(cur ^ 1, 0, P.na, P.nb, P.nc);
+        load_x(cur ^ 1, 0, P);
         float ev = 0.0f;
-        float *pcp = part + (cur ^ 1) * NW * 32;        // the previous tile's partial scores
+        float *pcp = partial_base(cur ^ 1);              // the previous tile's partial scores (this lane's store base)
         u32x4 fh, fm, fl, gh, gm, gl;            // this k-step's fragments, the next one's
         load_a(0, fh, fm, fl);
         __builtin_amdgcn_sched_barrier(0);
@@ -528,19 +547,19 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
         // also drains the vector-memory counter, i.e. it would wait out the two requests the first wavefront has just
         // made -- a full trip to memory per tile, with every other wavefront parked at the barrier meanwhile.
         UAVTRACK_LDS_BARRIER();
-        if (have_prev) final_sum(tile - G, pcp);
+        if (have_prev) final_sum(tile - G, part + (cur ^ 1) * NW * 32);
         accp = acc;
         have_prev = true;
         cur ^= 1;
     }
     if (have_prev) {                         // the last tile's epilogue has nothing left to hide behind
         float ev = 0.0f;
-        float *pcp = part + (cur ^ 1) * NW * 32;
+        float *pcp = partial_base(cur ^ 1);
         static_for<48>([&](auto ec) { epi_piece(accp, ev, ec, pcp); });
         __syncthreads();
         // (the last tile of this workgroup: blockIdx.x + G * (its tile count - 1))
         const unsigned last = blockIdx.x + ((ntiles - 1 - blockIdx.x) / G) * G;
-        final_sum(last, pcp);
+        final_sum(last, part + (cur ^ 1) * NW * 32);
     }
 }
 

@@ -1008,6 +1008,25 @@ def test_example_training_loop_runs(uavtrack):
     assert len(hist) == 3 and all(np.isfinite(h) for h in hist)
 
 
+def test_random_shapes_api_fuzz_slice(uavtrack):
+    """A fixed slice of tests/fuzz_api.py inside the suite (the full fuzzer is run by hand): random N, M, B, box, reward
+    mode, PMI width, workgroup size and action count; fused == stepwise bitwise for the given / greedy / actor rollouts,
+    MAAC-R vs the fp64 oracle, shard == unsharded."""
+    import fuzz_api
+    keys = ("UAVTRACK_WGS", "UAVTRACK_PMI_SCRATCH_MB")
+    saved = {k: os.environ.get(k) for k in keys}
+    try:
+        rng = np.random.RandomState(11)
+        for c in range(10):
+            fuzz_api.case(c, rng)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_create_destroy_does_not_leak_and_errors_are_reported(uavtrack, pmi_state_dict):
     """300 create / use / destroy cycles leave device memory where it was (every mode allocates its scratch);
     misuse comes back as RuntimeError with the library's message, never as a crash or a silent fallback."""
