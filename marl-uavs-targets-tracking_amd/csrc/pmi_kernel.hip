@@ -275,30 +275,22 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_in
 
 // Pieces of the three-way split of a float pair: its bf16 (truncated) parts as floats, those parts packed as
 // (low half: .x, high half: .y), and the exact remainder v - hi.
-__device__ __forceinline__ v2f bf16_part(v2f v)
+// Everything beside the MFMAs is SCALAR fp32 on purpose: a v_pk_fma_f32 / v_pk_add_f32 issued in an MFMA's shadow costs
+// ~11 cycles more than the two plain instructions it replaces (MI355X_MICROARCH.md, "price of one filler beside MFMAs"),
+// and this file is built with -fno-slp-vectorize so that the compiler does not re-pack them.
+constexpr __host__ __device__ int min_c(int a, int b) { return a < b ? a : b; }
+struct f2 { float x, y; };
+__device__ __forceinline__ f2 bf16_part(f2 v)
 {
-    return (v2f){__uint_as_float(__float_as_uint(v.x) & 0xFFFF0000u), __uint_as_float(__float_as_uint(v.y) & 0xFFFF0000u)};
+    return f2{__uint_as_float(__float_as_uint(v.x) & 0xFFFF0000u), __uint_as_float(__float_as_uint(v.y) & 0xFFFF0000u)};
 }
-__device__ __forceinline__ unsigned pack_hi16(v2f v)
+__device__ __forceinline__ unsigned pack_hi16(f2 v)
 {
     return __builtin_amdgcn_perm(__float_as_uint(v.y), __float_as_uint(v.x), 0x07060302u);
 }
-__device__ __forceinline__ v2f pk_sub(v2f v, v2f hi)
-{
-    v2f d;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(v), "v"(hi));
-    return d;
-}
-// ReLU of a pair
-__device__ __forceinline__ v2f relu2(v2f v) { return (v2f){fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f)}; }
-// (w.x, w.y) * x + (c.x, c.y), x being the low (HI = false) or high half of the register pair `xx`: one v_pk_fma_f32
-// whose op_sel does the broadcast
-template <bool HI>
-__device__ __forceinline__ v2f pk_fma_b(v2f w, v2f xx, v2f c)
-{
-    const float x = HI ? xx.y : xx.x;
-    return __builtin_elementwise_fma(w, (v2f){x, x}, c);
-}
+__device__ __forceinline__ f2 sub2(f2 v, f2 hi) { return f2{v.x - hi.x, v.y - hi.y}; }
+__device__ __forceinline__ f2 relu2(f2 v) { return f2{fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f)}; }
+__device__ __forceinline__ f2 fma2(f2 w, float x, f2 c) { return f2{fmaf(w.x, x, c.x), fmaf(w.y, x, c.y)}; }
 
 template <int H>
 __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams q)
@@ -348,21 +340,20 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
     const float bias1 = b1[col], wout = w2[col];
 
     // Branch layers (PMINet.py:50-55): thread (o2, pg) owns outputs 2 o2 and 2 o2 + 1 of each of the three branches
-    // for PPT of the tile's 32 pairs; its 30 folded weights and 6 biases stay in registers as (even, odd) pairs, so
-    // one packed instruction serves both outputs.
+    // for PPT of the tile's 32 pairs; its 30 folded weights and 6 biases stay in registers.
     const int o2 = tid % OP, pg = tid / OP;
-    v2f wc[5], wo[4], wb[3], bc, bo, bb;
+    f2 wc[5], wo[4], wb[3], bc, bo, bb;
     {
         const int o = 2 * o2;
 #pragma unroll
-        for (int v = 0; v < 5; ++v) wc[v] = (v2f){q.blob[v * H + o], q.blob[v * H + o + 1]};
-        bc = (v2f){q.blob[5 * H + o], q.blob[5 * H + o + 1]};
+        for (int v = 0; v < 5; ++v) wc[v] = f2{q.blob[v * H + o], q.blob[v * H + o + 1]};
+        bc = f2{q.blob[5 * H + o], q.blob[5 * H + o + 1]};
 #pragma unroll
-        for (int v = 0; v < 4; ++v) wo[v] = (v2f){q.blob[6 * H + v * H + o], q.blob[6 * H + v * H + o + 1]};
-        bo = (v2f){q.blob[10 * H + o], q.blob[10 * H + o + 1]};
+        for (int v = 0; v < 4; ++v) wo[v] = f2{q.blob[6 * H + v * H + o], q.blob[6 * H + v * H + o + 1]};
+        bo = f2{q.blob[10 * H + o], q.blob[10 * H + o + 1]};
 #pragma unroll
-        for (int v = 0; v < 3; ++v) wb[v] = (v2f){q.blob[11 * H + v * H + o], q.blob[11 * H + v * H + o + 1]};
-        bb = (v2f){q.blob[14 * H + o], q.blob[14 * H + o + 1]};
+        for (int v = 0; v < 3; ++v) wb[v] = f2{q.blob[11 * H + v * H + o], q.blob[11 * H + v * H + o + 1]};
+        bb = f2{q.blob[14 * H + o], q.blob[14 * H + o + 1]};
     }
     // where this thread's outputs live in a plane's row: concat order comm | obs | boundary_state (PMINet.py:58)
     const int arow0 = (pg * PPT) * PITCH + 4 * o2;
@@ -404,7 +395,7 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
     // kMicro atoms of one or two instructions, so that the main loop can deal them out evenly behind its MFMAs (see
     // there).  The inputs of the next pair are requested by atom kLoadAtom, once this pair's FMAs have consumed theirs.
     constexpr int kMicro = 37, kLoadAtom = 20;
-    struct Prod { float4 x[3]; v2f v[3], hi[3]; };      // inputs; the three branches' output pairs / remainders; their bf16 parts
+    struct Prod { float4 x[3]; f2 v[3], hi[3]; };      // inputs; the three branches' output pairs / remainders; their bf16 parts
     auto load_x = [&](int xbuf, int pp, Prod &P) {
         const float4 *xp = reinterpret_cast<const float4 *>(xs + xbuf * 32 * 12 + (pg * PPT + pp) * 12);
         P.x[0] = xp[0]; P.x[1] = xp[1]; P.x[2] = xp[2];
@@ -413,21 +404,25 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
         constexpr int op = decltype(opc)::value;
         unsigned char *dst = aplanes + abuf * 3 * PLANE + arow0 + pp * PITCH;
         if constexpr (op < 12) {
-            // FMA `op` of the 12: input i = op of x = (la_i * la_j)[0..11]; branch comm takes 0..4, obs 5..8, boundary 9..11
-            constexpr int br = op < 5 ? 0 : op < 9 ? 1 : 2, first = op == 0 || op == 5 || op == 9;
-            const float4 &f = P.x[op / 4];
-            const v2f xx = (op % 4) / 2 ? (v2f){f.z, f.w} : (v2f){f.x, f.y};
-            const v2f wgt = br == 0 ? wc[op] : br == 1 ? wo[op - 5] : wb[op - 9];
-            const v2f bias = br == 0 ? bc : br == 1 ? bo : bb;
-            P.v[br] = pk_fma_b<(op % 2) != 0>(wgt, xx, first ? bias : P.v[br]);
+            // FMA number `op`, the three branches taking turns (a branch's chain is dependent: its next FMA comes two
+            // atoms later).  Input i of x = (la_i * la_j)[0..11]: branch comm takes 0..4, obs 5..8, boundary 9..11.
+            constexpr int br = op < 9 ? op % 3 : op < 11 ? op - 9 : 0;          // c o b  c o b  c o b  c o  c
+            constexpr int kk = op < 9 ? op / 3 : op < 11 ? 3 : 4;               // position inside the branch's chain
+            constexpr int i = br == 0 ? kk : br == 1 ? 5 + kk : 9 + kk;
+            const float4 &f = P.x[i / 4];
+            const float xi = i % 4 == 0 ? f.x : i % 4 == 1 ? f.y : i % 4 == 2 ? f.z : f.w;
+            const f2 wgt = br == 0 ? wc[kk] : br == 1 ? wo[kk] : wb[kk];
+            const f2 bias = br == 0 ? bc : br == 1 ? bo : bb;
+            P.v[br] = fma2(wgt, xi, kk == 0 ? bias : P.v[br]);
         } else if constexpr (op < 15) {
             P.v[op - 12] = relu2(P.v[op - 12]);
         } else if constexpr (op < 33) {
-            // planes 0 (hi) and 1 (mid), branch by branch: bf16 parts, packed store, exact remainder
-            constexpr int q = op - 15, pl = q / 9, br = (q % 9) / 3, step = q % 3;
+            // planes 0 (hi) and 1 (mid): bf16 parts, packed store, exact remainder -- each step for the three branches
+            // in turn, so that no atom waits for the one just before it
+            constexpr int q = op - 15, pl = q / 9, step = (q % 9) / 3, br = q % 3;
             if constexpr (step == 0) P.hi[br] = bf16_part(P.v[br]);
             else if constexpr (step == 1) *reinterpret_cast<unsigned *>(dst + pl * PLANE + br * 2 * H) = pack_hi16(P.v[br]);
-            else P.v[br] = pk_sub(P.v[br], P.hi[br]);
+            else P.v[br] = sub2(P.v[br], P.hi[br]);
         } else if constexpr (op < 36) {
             constexpr int br = op - 33;     // plane 2 (lo): what is left, truncated
             *reinterpret_cast<unsigned *>(dst + 2 * PLANE + br * 2 * H) = pack_hi16(P.v[br]);
@@ -463,15 +458,23 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
 
     // ReLU, fc2 (PMINet.py:60-61) of a finished tile, row r of this wavefront's 16: sum over the block's 32 columns in
     // a fixed butterfly order (bitwise reproducible).  Three pieces, so the main loop can hide them too.
-    auto epi_piece = [&](const f32x16 &a, float &ev, auto ec, float *pc) {
-        constexpr int e = decltype(ec)::value, r = e / 3;
-        if constexpr (e % 3 == 0) { ev = fmaxf(a[r], 0.0f) * wout; ev = dpp_add<0xB1>(ev); }
-        else if constexpr (e % 3 == 1) { ev = dpp_add<0x4E>(ev); ev = dpp_add<0x141>(ev); }
-        else {
-            ev = dpp_add<0x140>(ev); ev = dpp_add<0x142, 0xa>(ev);
-            // C/D layout of 32x32 MFMA: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).  Every lane stores: `pc` is the
-            // writer lane's slot base and a private sink for the others (no exec-mask juggling between the MFMAs).
-            pc[(r & 3) + 8 * (r >> 2)] = ev;
+    auto epi_piece = [&](const f32x16 &a, float (&ev)[2], auto ec, float *pc) {
+        // piece e: step e % 6 of rows 2 (e / 6) and 2 (e / 6) + 1 -- two independent chains per piece
+        constexpr int e = decltype(ec)::value, st = e % 6;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = 2 * (e / 6) + u;
+            if constexpr (st == 0) ev[u] = fmaxf(a[r], 0.0f) * wout;
+            else if constexpr (st == 1) ev[u] = dpp_add<0xB1>(ev[u]);
+            else if constexpr (st == 2) ev[u] = dpp_add<0x4E>(ev[u]);
+            else if constexpr (st == 3) ev[u] = dpp_add<0x141>(ev[u]);
+            else if constexpr (st == 4) ev[u] = dpp_add<0x140>(ev[u]);
+            else {
+                ev[u] = dpp_add<0x142, 0xa>(ev[u]);
+                // C/D layout of 32x32 MFMA: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).  Every lane stores: `pc` is
+                // the writer lane's slot base and a private sink for the others (no exec-mask juggling between the MFMAs).
+                pc[(r & 3) + 8 * (r >> 2)] = ev[u];
+            }
         }
     };
     auto partial_base = [&](int buf) {
@@ -507,7 +510,7 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
         };
         Prod P;
         load_x(cur ^ 1, 0, P);
-        float ev = 0.0f;
+        float ev[2] = {0.0f, 0.0f};
         float *pcp = partial_base(cur ^ 1);              // the previous tile's partial scores (this lane's store base)
         u32x4 fh, fm, fl, gh, gm, gl;            // this k-step's fragments, the next one's
         load_a(0, fh, fm, fl);
@@ -521,7 +524,15 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
             static_for<6>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 constexpr int slot = 6 * (s - s0) + t;
-                constexpr int lo = slot * kMicro / nslot, hi = (slot + 1) * kMicro / nslot;
+                // Which atoms ride behind this MFMA.  Three k-steps per pair (H = 128): a hand-balanced deal -- the slot
+                // that also issues the next k-step's three fragment reads (t = 0) takes one atom, the first of the two that carry an
+                // epilogue piece (t = 1, 4) one, the others two or three -- so that every gap holds five to seven
+                // plain instructions: a gap shorter than the MFMA's 32 cycles idles the wavefront, a longer one idles
+                // the matrix core.  Other widths: evenly by count.
+                constexpr bool kTuned = KS == 3 * PPT;
+                constexpr int pre[7] = {0, 1, 2, 5, 8, 10, 13};
+                constexpr int lo = kTuned ? min_c(kMicro, (slot / 6) * 13 + pre[slot % 6]) : slot * kMicro / nslot;
+                constexpr int hi = kTuned ? min_c(kMicro, (slot / 6) * 13 + pre[slot % 6 + 1]) : (slot + 1) * kMicro / nslot;
                 const bf16x8 a = as_bf16x8(t == 1 ? fl : (t == 2 || t == 4) ? fm : fh);
                 const bf16x8 bq = as_bf16x8(t == 0 ? Bl[s] : (t == 2 || t == 3) ? Bm[s] : Bh[s]);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc, 0, 0, 0);
@@ -530,7 +541,9 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
                     if constexpr (decltype(opc)::value >= lo && decltype(opc)::value < hi) micro(P, opc, cur ^ 1, cur ^ 1, pp);
                 });
                 // the previous tile's epilogue: 48 pieces over the 6 KS slots
-                constexpr int gslot = 6 * s + t, elo = gslot * 48 / (6 * KS), ehi = (gslot + 1) * 48 / (6 * KS);
+                constexpr int gslot = 6 * s + t;
+                constexpr int elo = kTuned ? (t == 1 ? 2 * s : t == 4 ? 2 * s + 1 : 0) : gslot * 48 / (6 * KS);
+                constexpr int ehi = kTuned ? (t == 1 || t == 4 ? elo + 1 : 0) : (gslot + 1) * 48 / (6 * KS);
                 static_for<48>([&](auto ec) {
                     if constexpr (decltype(ec)::value >= elo && decltype(ec)::value < ehi) epi_piece(accp, ev, ec, pcp);
                 });
@@ -553,7 +566,7 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
         cur ^= 1;
     }
     if (have_prev) {                         // the last tile's epilogue has nothing left to hide behind
-        float ev = 0.0f;
+        float ev[2] = {0.0f, 0.0f};
         float *pcp = partial_base(cur ^ 1);
         static_for<48>([&](auto ec) { epi_piece(accp, ev, ec, pcp); });
         __syncthreads();
