@@ -665,21 +665,27 @@ struct EpParams {
     const float *reward, *terms;     // [S][B][N], [S][3][B][N] (terms nullable)
     const int32_t *covered;          // [S][B] (nullable)
     float *ep_sums;                  // [B][5]
-    int32_t S, B, N, E, add;
+    int32_t S, B, N, E, add, K;      // K: lanes (step slices) per UAV
 };
 
+// Episode sums of a chunk (train.py:181-192).  K lanes per (environment, UAV), each summing every K-th
+// step; the slices, then the UAVs, are added in a fixed order (bitwise reproducible).  (One lane per UAV walking all
+// S steps left the chip mostly idle: 342 workgroups of dependent loads, 93 us per 100-step chunk at 4096 x 20.)
+constexpr int kEpSlices = 4;      // K for swarms of up to kMaxWorkgroup / 4 UAVs (launch_ep_sums)
 __global__ void __launch_bounds__(kMaxWorkgroup) ep_sums_kernel(const EpParams q)
 {
-    extern __shared__ float4 red4[];
+    extern __shared__ float4 red4[];                 // [E * N][K]
+    const int K = q.K;
     const int tid = threadIdx.x, N = q.N;
     const int env0 = blockIdx.x * q.E;
     const int envs_here = min(q.E, q.B - env0);
-    const int e = tid / N, i = tid - e * N;
-    const bool active = tid < q.E * N && e < envs_here;
+    const int sl = tid % K, ag = tid / K;            // slice, (environment, UAV) of this lane
+    const int e = ag / N, i = ag - e * N;
+    const bool active = ag < q.E * N && e < envs_here;
     const size_t BN = (size_t)q.B * N, g = (size_t)(env0 + e) * N + i;
     float4 acc = make_float4(0, 0, 0, 0);
     if (active) {
-        for (int t = 0; t < q.S; ++t) {
+        for (int t = sl; t < q.S; t += K) {
             acc.x += q.reward[(size_t)t * BN + g];
             if (q.terms) {
                 const float *tp = q.terms + (size_t)t * 3 * BN + g;
@@ -689,9 +695,13 @@ __global__ void __launch_bounds__(kMaxWorkgroup) ep_sums_kernel(const EpParams q
         red4[tid] = acc;
     }
     __syncthreads();
-    if (active && i == 0) {
+    if (active && i == 0 && sl == 0) {
         float4 s = make_float4(0, 0, 0, 0);
-        for (int j = 0; j < N; ++j) { const float4 v = red4[e * N + j]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        for (int j = 0; j < N; ++j)
+            for (int k = 0; k < K; ++k) {
+                const float4 v = red4[(e * N + j) * K + k];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
         float cov = 0.0f;
         if (q.covered)
             for (int t = 0; t < q.S; ++t) cov += (float)q.covered[(size_t)t * q.B + env0 + e];
@@ -811,9 +821,12 @@ hipError_t launch_ep_sums(const uavtrack_env *env, int steps, const float *rewar
                           const int32_t *covered, float *ep_sums, bool add, hipStream_t stream)
 {
     const uavtrack_config &c = env->cfg;
-    const int wgs = c.n_uav <= 256 ? 256 : kMaxWorkgroup;
-    EpParams q{reward, terms, covered, ep_sums, steps, c.n_envs, c.n_uav, wgs / c.n_uav, add ? 1 : 0};
-    const size_t lds = (size_t)q.E * q.N * 16;
+    // kEpSlices lanes per UAV where a workgroup has them, fewer for the largest swarms
+    int K = kEpSlices;
+    while (K > 1 && c.n_uav * K > kMaxWorkgroup) K >>= 1;
+    const int wgs = c.n_uav * K <= 256 ? 256 : kMaxWorkgroup;
+    EpParams q{reward, terms, covered, ep_sums, steps, c.n_envs, c.n_uav, wgs / (c.n_uav * K), add ? 1 : 0, K};
+    const size_t lds = (size_t)q.E * q.N * K * 16;
     hipLaunchKernelGGL(ep_sums_kernel, dim3((unsigned)((c.n_envs + q.E - 1) / q.E)), dim3(wgs), lds, stream, q);
     return hipGetLastError();
 }

@@ -542,6 +542,30 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     __syncthreads();
     if (one_target_per_lane && my_target) { ttx = tgt[0]; tty = tgt[2]; ttc = tgt[4]; tts = tgt[6]; tth = thd[tid]; }
 
+    // MAAC-R pair emission, one step behind (N <= 64, specialised shapes): a workgroup reserves its slots of the pair
+    // list with ONE returning global atomic per step; waiting for it on the spot put a trip to L2 on every step's
+    // critical path, so the reservation made at step t is consumed at step t + 1 (and behind the loop): these hold
+    // what step t's lanes need to write their records and pairs then.
+    constexpr bool kPipeEmit = MODE == UAVTRACK_REWARD_PMI && N_ > 0 && N_ <= 64;
+    unsigned pe_base = 0, pe_tg = 0;        // (thread 0) the reservation in flight; flat [t][b][i] of the pending step
+    int pe_mine = 0, pe_slot = 0;
+    unsigned long long pe_nball = 0, pe_later = 0;
+    float pe_raw = 0.0f;
+    auto commit_pairs = [&](unsigned base) {
+        const unsigned first = base + (unsigned)pe_slot;
+        uint32_t *rec = p.nbrec + (size_t)pe_tg * (nbrec_mask_words(N) + 2);
+        *reinterpret_cast<uint4 *>(rec) = make_uint4((unsigned)pe_nball, (unsigned)(pe_nball >> 32), first, __float_as_uint(pe_raw));
+        if (pe_mine) {
+            uint2 *dst = p.pairs + first;
+            unsigned long long later = pe_later;
+            while (later) {                      // ascending j
+                const int j = __ffsll((long long)later) - 1;
+                later &= later - 1;
+                *dst++ = make_uint2(pe_tg, (unsigned)j);
+            }
+        }
+    };
+
     for (int t = 0; t < p.T; ++t) {
         const unsigned tg_off = (unsigned)t * (unsigned)BN + g32;   // flat [t][b][i] (MAAC-R pair records; < 2^32 by ensure_pmi_scratch)
         const int cbuf = (t & 1) * E * CW;
@@ -843,6 +867,26 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         // ---- MAAC-R only: emit the neighbour pairs (i < j, d <= dp on post-move poses, uav.py:278) this
         //      workgroup owns into the global pair list the PMI scoring kernel consumes.  s_ij = s_ji
         //      (the input is la_i * la_j), so unordered pairs halve the work.
+        if (kPipeEmit) {
+            unsigned *wg_cnt = covw + 2 * E * CW;          // two extra words behind the coverage masks
+            if (tid == 0) {
+                if (t > 0) wg_cnt[1] = pe_base;            // last step's reservation has had a whole step to arrive
+                wg_cnt[0] = 0;
+            }
+            __syncthreads();
+            if (t > 0 && active) commit_pairs(wg_cnt[1]);
+            int mine = 0, slot = 0;
+            unsigned long long nball = 0, later = 0;        // all neighbours / neighbours j > i
+            if (active) {
+                nball = nbmask & ~(1ull << i);
+                later = (i + 1 < 64) ? (nball >> (i + 1)) << (i + 1) : 0ull;
+                mine = __popcll(later);
+                if (mine) slot = (int)atomicAdd(&wg_cnt[0], (unsigned)mine);
+            }
+            __syncthreads();
+            if (tid == 0) pe_base = wg_cnt[0] ? atomicAdd(p.pair_count, wg_cnt[0]) : 0u;
+            pe_mine = mine; pe_slot = slot; pe_nball = nball; pe_later = later; pe_tg = tg_off; pe_raw = raw;
+        } else
         if (MODE == UAVTRACK_REWARD_PMI) {
             unsigned *wg_cnt = covw + 2 * E * CW;          // two extra words behind the coverage masks
             if (tid == 0) wg_cnt[0] = 0;
@@ -956,6 +1000,12 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         pn ^= 1;
         row += BN;
         rowb += (size_t)p.B;
+    }
+    if (kPipeEmit && p.T > 0) {              // the last step's records and pairs
+        unsigned *wg_cnt = covw + 2 * E * CW;
+        if (tid == 0) wg_cnt[1] = pe_base;
+        __syncthreads();
+        if (active) commit_pairs(wg_cnt[1]);
     }
     if (CW == 1 && active && i == 0) {       // the last step's deferred coverage count
         const int cov = __popc(cov_pending);

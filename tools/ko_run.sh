@@ -1,11 +1,13 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-OUT=gpurun_out/x6_r02.log
+OUT=gpurun_out/chk_r02.log
 : > $OUT
-timeout -k 10 600 python3 -m pytest tests -x -q -m gpu -k "pmi or baseline or auto_reset or fused_actor or fuzz" > gpurun_out/pytest_gpu.log 2>&1
+timeout -k 10 900 python3 -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest rc=$?" >> $OUT
-tail -4 gpurun_out/pytest_gpu.log >> $OUT
+tail -5 gpurun_out/pytest_gpu.log >> $OUT
+timeout -k 10 600 python3 tests/fuzz_api.py 80 > gpurun_out/fuzz.log 2>&1
+echo "fuzz rc=$? $(tail -1 gpurun_out/fuzz.log)" >> $OUT
 for i in 1 2; do
 timeout -k 10 300 python3 bench.py --reward pmi --steps 400 --warmup 200 --no-extras --no-cpu-baseline > gpurun_out/bench_pmi.json 2> gpurun_out/bench_pmi.err
 python3 - >> $OUT <<'PY'
