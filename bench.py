@@ -434,7 +434,10 @@ def extras(uavtrack, args, B, device, bytes_unit):
         "note": "uavtrack_step eager from Python/ctypes, best of three 400-step runs; host-launch bound",
     }
     # a batch that fills the chip (SURVEY 8d 'bandwidth-saturating batch'), measured like the roofline leg
-    Bs, Ts = 65536, 50
+    # (200-step launches like the headline leg when the 17 GB of outputs fit comfortably; 50-step launches otherwise --
+    # they carry the kernel's start-up cost four times as often and read ~15 % lower)
+    free_b, _ = torch.cuda.mem_get_info(device)
+    Bs, Ts = 65536, (200 if free_b > (64 << 30) else 50)
     rs = roofline_leg(uavtrack, args, Bs, device, T=Ts, launches=4)
     ach = bytes_unit * Bs * N * Ts / (rs["avg_ms"] * 1e-3) / 1e9
     out["saturating_batch"] = {
