@@ -1,21 +1,23 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-OUT=gpurun_out/final_r02.log
+OUT=gpurun_out/x6_r02.log
 : > $OUT
-timeout -k 10 300 python3 -c "import __graft_entry__ as g; g.smoke()" >> $OUT 2>&1
-echo "smoke rc=$?" >> $OUT
-timeout -k 10 400 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_k20.json 2> gpurun_out/bench_k20.err
-echo "bench k20 rc=$?" >> $OUT
-timeout -k 10 400 python3 bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
-echo "bench default rc=$?" >> $OUT
+timeout -k 10 600 python3 -m pytest tests -x -q -m gpu -k "pmi or baseline or auto_reset or fused_actor or fuzz or example" > gpurun_out/pytest_gpu.log 2>&1
+echo "pytest rc=$?" >> $OUT
+tail -4 gpurun_out/pytest_gpu.log >> $OUT
+for w in 0 128 64; do
+UAVTRACK_WGS=$w timeout -k 10 300 python3 bench.py --reward pmi --steps 400 --warmup 200 --no-extras --no-cpu-baseline > gpurun_out/bench_pmi.json 2> gpurun_out/bench_pmi.err
+python3 - $w >> $OUT <<'PY'
+import json,sys
+d=json.loads(open("gpurun_out/bench_pmi.json").read().strip().splitlines()[-1])
+print("wgs",sys.argv[1], d["value"]/1e9, "G", d["roofline"]["avg_launch_ms"])
+PY
+done
+timeout -k 10 300 python3 bench.py --reward pmi --rollout 1 --steps 400 --warmup 100 --no-extras --no-cpu-baseline > gpurun_out/bench_pmi1.json 2> gpurun_out/bench_pmi1.err
 python3 - >> $OUT <<'PY'
 import json
-for f in ("bench_k20","bench_default"):
-    d=json.loads(open(f"gpurun_out/{f}.json").read().strip().splitlines()[-1])
-    r=d["roofline"]
-    print(f, round(d["value"]/1e9,2),"G ms/step",round(d["ms_per_step"],5),"| roofline frac",round(r["frac"],3),"launch ms",round(r["avg_launch_ms"],4),"| cpu",round(d["cpu_baseline"]["value"]/1e6,1),"M", "| launch:",d["config"]["launch"][:90])
-    for k in ("saturating_batch","closed_loop","per_step_launch"):
-        if k in d: print("   ",k, json.dumps(d[k])[:300])
+d=json.loads(open("gpurun_out/bench_pmi1.json").read().strip().splitlines()[-1])
+print("T=1:", d["value"]/1e9, "G", d["ms_per_step"])
 PY
-grep -v amdgpu.ids $OUT
+cat $OUT
