@@ -782,6 +782,13 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             raw = p.alpha * tt + p.beta * bp + p.gamma * dupn;
             if (MODE != UAVTRACK_REWARD_RAW) rawl[e * (N + 1) + i] = raw;
         }
+        if (kPipeEmit && tid == 0) {
+            // MAAC-R: the reservation made a step ago is taken HERE, ahead of this step's output stores -- its wait
+            // drains the vector-memory counter, and behind the stores that would be a wait for all of them
+            unsigned *wg_cnt = covw + 2 * E * CW;
+            wg_cnt[0] = 0;
+            if (t > 0) wg_cnt[1] = pe_base;
+        }
         UAVTRACK_STEP_BARRIER();
 
         // ---- P4: cooperative reward, coverage, outputs
@@ -869,11 +876,8 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         //      (the input is la_i * la_j), so unordered pairs halve the work.
         if (kPipeEmit) {
             unsigned *wg_cnt = covw + 2 * E * CW;          // two extra words behind the coverage masks
-            if (tid == 0) {
-                if (t > 0) wg_cnt[1] = pe_base;            // last step's reservation has had a whole step to arrive
-                wg_cnt[0] = 0;
-            }
-            __syncthreads();
+            // (thread 0 zeroed wg_cnt[0] and published the previous step's reservation in wg_cnt[1] ahead of the
+            // P3 -> P4 barrier: one barrier of its own is all this block needs)
             if (t > 0 && active) commit_pairs(wg_cnt[1]);
             int mine = 0, slot = 0;
             unsigned long long nball = 0, later = 0;        // all neighbours / neighbours j > i
