@@ -1,14 +1,13 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-OUT=gpurun_out/ko_r02.log
+OUT=gpurun_out/final_r02.log
 : > $OUT
-for v in k_base k_lds k_bar k_gat k_rec k_all k_base; do
-UAVTRACK_LIB=build_variants/$v.so timeout -k 10 300 python3 bench.py --reward pmi --steps 400 --warmup 200 --no-extras --no-cpu-baseline > gpurun_out/bench_pmi.json 2> gpurun_out/bench_pmi.err
-python3 - $v >> $OUT <<'PY'
-import json,sys
-d=json.loads(open("gpurun_out/bench_pmi.json").read().strip().splitlines()[-1])
-print(sys.argv[1], d["value"]/1e9, "G", d["roofline"]["avg_launch_ms"], d["roofline"]["pairs_scored"])
-PY
-done
+timeout -k 10 900 python3 -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu.log 2>&1
+echo "pytest rc=$?" >> $OUT
+tail -4 gpurun_out/pytest_gpu.log >> $OUT
+timeout -k 10 600 python3 tests/fuzz_api.py 60 > gpurun_out/fuzz.log 2>&1
+echo "fuzz rc=$? $(tail -1 gpurun_out/fuzz.log)" >> $OUT
 cat $OUT
+PROFILE_MFMA=1 bash tools/profile_gpu.sh r02pmi --reward pmi --steps 1000 --warmup 200 --no-cpu-baseline --no-extras > gpurun_out/prof_r02pmi.log 2>&1
+echo "profile rc=$?"
