@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
     // One pair of the branch layers -- 12 packed FMAs, ReLU, three-way split, nine 4-byte LDS writes -- as a list of
     // kMicro atoms of one or two instructions, so that the main loop can deal them out evenly behind its MFMAs (see
     // there).  The inputs of the next pair are requested by atom kLoadAtom, once this pair's FMAs have consumed theirs.
-    constexpr int kMicro = 37, kLoadAtom = 20;
+    constexpr int kMicro = 36, kLoadAtom = 20;
     struct Prod { float4 x[3]; f2 v[3], hi[3]; };      // inputs; the three branches' output pairs / remainders; their bf16 parts
     auto load_x = [&](int xbuf, int pp, Prod &P) {
         const float4 *xp = reinterpret_cast<const float4 *>(xs + xbuf * 32 * 12 + (pg * PPT + pp) * 12);
@@ -480,12 +480,15 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
     auto partial_base = [&](int buf) {
         return (lane & 31) == 16 ? part + buf * NW * 32 + w * 32 + 4 * kh : sink + w * 96 + lane;
     };
+    // (by the LAST wavefront's first 32 lanes: the first wavefront already carries the input pipeline, and whoever is
+    // late holds the others at the tile barrier)
+    const int ft = tid - (NW - 1) * 64;
     auto final_sum = [&](unsigned tile, const float *pc) {      // over the column blocks, in order
-        if (tid < 32 && tile * 32 + tid < npairs) {
+        if (ft >= 0 && ft < 32 && tile * 32 + ft < npairs) {
             float sc = b2;
 #pragma unroll
-            for (int ww = 0; ww < NW; ++ww) sc += pc[ww * 32 + tid];
-            q.scores[tile * 32 + tid] = sc;                     // the pair's own slot: s_ij = s_ji is stored once
+            for (int ww = 0; ww < NW; ++ww) sc += pc[ww * 32 + ft];
+            q.scores[tile * 32 + ft] = sc;                      // the pair's own slot: s_ij = s_ji is stored once
         }
     };
 
@@ -525,14 +528,15 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
                 constexpr int t = decltype(tc)::value;
                 constexpr int slot = 6 * (s - s0) + t;
                 // Which atoms ride behind this MFMA.  Three k-steps per pair (H = 128): a hand-balanced deal -- the slot
-                // that also issues the next k-step's three fragment reads (t = 0) takes one atom, the first of the two that carry an
-                // epilogue piece (t = 1, 4) one, the others two or three -- so that every gap holds five to seven
+                // that also issues the next k-step's three fragment reads (t = 0) takes two atoms, the two that carry an
+                // epilogue piece (t = 1, 4) one, the others three (two in the pair's last k-step) -- so that every gap holds five to seven
                 // plain instructions: a gap shorter than the MFMA's 32 cycles idles the wavefront, a longer one idles
                 // the matrix core.  Other widths: evenly by count.
                 constexpr bool kTuned = KS == 3 * PPT;
-                constexpr int pre[7] = {0, 1, 2, 5, 8, 10, 13};
-                constexpr int lo = kTuned ? min_c(kMicro, (slot / 6) * 13 + pre[slot % 6]) : slot * kMicro / nslot;
-                constexpr int hi = kTuned ? min_c(kMicro, (slot / 6) * 13 + pre[slot % 6 + 1]) : (slot + 1) * kMicro / nslot;
+                // atoms per slot: k-steps 0 and 1 of a pair {2,1,3,3,1,3} (13 each), k-step 2 {2,1,2,2,1,2} (the last 10)
+                constexpr int pre[7] = {0, 2, 3, 6, 9, 10, 13}, pre2[7] = {26, 28, 29, 31, 33, 34, 36};
+                constexpr int lo = !kTuned ? slot * kMicro / nslot : slot < 12 ? (slot / 6) * 13 + pre[slot % 6] : pre2[slot - 12];
+                constexpr int hi = !kTuned ? (slot + 1) * kMicro / nslot : slot < 12 ? (slot / 6) * 13 + pre[slot % 6 + 1] : pre2[slot - 11];
                 const bf16x8 a = as_bf16x8(t == 1 ? fl : (t == 2 || t == 4) ? fm : fh);
                 const bf16x8 bq = as_bf16x8(t == 0 ? Bl[s] : (t == 2 || t == 3) ? Bm[s] : Bh[s]);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc, 0, 0, 0);
