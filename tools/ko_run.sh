@@ -1,13 +1,16 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-OUT=gpurun_out/final_r02.log
+OUT=gpurun_out/st_r02.log
 : > $OUT
-timeout -k 10 900 python3 -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu.log 2>&1
-echo "pytest rc=$?" >> $OUT
-tail -4 gpurun_out/pytest_gpu.log >> $OUT
-timeout -k 10 600 python3 tests/fuzz_api.py 60 > gpurun_out/fuzz.log 2>&1
-echo "fuzz rc=$? $(tail -1 gpurun_out/fuzz.log)" >> $OUT
+for v in st_1 st_2 st_3; do
+UAVTRACK_LIB=build_variants/$v.so timeout -k 10 300 python3 bench.py --reward pmi --steps 400 --warmup 200 --no-extras --no-cpu-baseline > gpurun_out/bench_pmi.json 2> gpurun_out/bench_pmi.err
+python3 - $v >> $OUT <<'PY'
+import json,sys
+d=json.loads(open("gpurun_out/bench_pmi.json").read().strip().splitlines()[-1])
+v=int(d["roofline"]["pairs_scored"])
+tiles=v>>44; cyc=v&((1<<44)-1)
+print(sys.argv[1], "launch ms", d["roofline"]["avg_launch_ms"], "tiles", tiles, "cycles", cyc, "per tile", cyc/max(tiles,1))
+PY
+done
 cat $OUT
-PROFILE_MFMA=1 bash tools/profile_gpu.sh r02pmi --reward pmi --steps 1000 --warmup 200 --no-cpu-baseline --no-extras > gpurun_out/prof_r02pmi.log 2>&1
-echo "profile rc=$?"
