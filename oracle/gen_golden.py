@@ -13,6 +13,7 @@ Scenarios:
   g2  N20 M10  coop 0   (MAAC)   8 seeds x 50 steps
   g3  N20 M10  coop .3  (MAAC-G) 8 seeds x 50 steps
   g4  N20 M10  coop .3  PMI H128 8 seeds x 50 steps   (MAAC-R)
+  g4b N20 M10  coop .3  PMI H64  4 seeds x 25 steps   (MAAC-R at PMINetwork's default hidden_dim, PMINet.py:21)
   g5a N50 M25  coop 0            4 seeds x 25 steps
   g5b N50 M25  coop .3  PMI      4 seeds x 25 steps
   g6  reset-only layouts N in {5,10,20,50}
@@ -285,12 +286,24 @@ def gen_greedy():
     save("greedy_ref", arrays, meta)
 
 
+def gen_h64():
+    """MAAC-R with PMINetwork at its class-default width (PMINet.py:21, hidden_dim=64): weights + a short scenario."""
+    pmi = make_pmi(64, 43)
+    sd = {k: v.detach().numpy().astype(np.float32) for k, v in pmi.state_dict().items()
+          if "num_batches_tracked" not in k}
+    save("pmi_h64", sd, dict(hidden=64, bn_eps=1e-5, torch_seed=43))
+    scenario("g4b_n20m10_pmi_h64", 20, 10, 0.3, pmi, [52, 53, 54, 55], 25)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--only-actor":
         gen_actor()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "--only-greedy":
         gen_greedy()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-h64":
+        gen_h64()
         return
     pmi = make_pmi(128, 42)
     sd = {k: v.detach().numpy().astype(np.float32) for k, v in pmi.state_dict().items()
@@ -307,6 +320,7 @@ def main():
     gen_edges(pmi)
     gen_actor()
     gen_greedy()
+    gen_h64()       # (last: nothing above depends on what it does to the global RNGs)
 
 
 if __name__ == "__main__":

@@ -28,3 +28,11 @@ def load_golden(name):
 def pmi_state_dict():
     z = np.load(os.path.join(GOLDEN, "pmi_h128.npz"))
     return {k: z[k] for k in z.files if k != "meta"}
+
+
+@pytest.fixture(scope="session")
+def pmi_state_dict_h64():
+    """PMINetwork at its class-default width (PMINet.py:21), recorded from the reference (gen_golden.py: gen_h64)."""
+    z = np.load(os.path.join(GOLDEN, "pmi_h64.npz"))
+    return {k: z[k] for k in z.files if k != "meta"}
+

@@ -197,17 +197,19 @@ def test_pmi_reward_teacher_forced_vs_oracle(uavtrack, pmi_state_dict, N, M, B, 
     assert saw_pairs > 0       # neighbours existed, so the network really ran
 
 
-def test_pmi_against_reference_goldens(uavtrack, pmi_state_dict):
-    """HIP MAAC-R reward vs the REAL reference's recorded rewards (g4: N20 M10, g5b: N50 M25)."""
-    for name in ("g4_n20m10_pmi", "g5b_n50m25_pmi"):
+def test_pmi_against_reference_goldens(uavtrack, pmi_state_dict, pmi_state_dict_h64):
+    """HIP MAAC-R reward vs the REAL reference's recorded rewards (g4: N20 M10 H128, g5b: N50 M25 H128, g4b: N20 M10 at
+    PMINetwork's default hidden_dim 64)."""
+    for name in ("g4_n20m10_pmi", "g5b_n50m25_pmi", "g4b_n20m10_pmi_h64"):
         z, meta = load_golden(name)
+        sd = pmi_state_dict_h64 if name.endswith("h64") else pmi_state_dict
         N, M = meta["n_uav"], meta["m_targets"]
         E, T = len(meta["seeds"]), meta["steps"]
         B = E * T
         pick = lambda k: z[k][:, :T].reshape(B, -1)
         kw = dict(n_envs=B, n_uav=N, m_targets=M, cooperative=0.3)
         env = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(reward_mode=uavtrack.RewardMode.PMI, **kw))
-        env.set_pmi(pmi_state_dict)
+        env.set_pmi(sd)
         env.set_state(**{k: pick(k) for k in ("ux", "uy", "uh", "ua", "tx", "ty", "th")})
         act = z["actions"].reshape(B, N).astype(np.int32)
         orc = OracleEnv(OracleConfig(**kw), n_threads=8)

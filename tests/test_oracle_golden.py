@@ -54,6 +54,14 @@ def test_teacher_forced(name, pmi_state_dict):
         check_episode(z, "", e, meta, pmi_state_dict, meta["steps"])
 
 
+def test_teacher_forced_pmi_default_width(pmi_state_dict_h64):
+    """MAAC-R with PMINetwork(hidden_dim=64), the class default (PMINet.py:21): oracle vs the reference's outputs."""
+    z, meta = load_golden("g4b_n20m10_pmi_h64")
+    assert int(z["overstep_prints"].sum()) == 0
+    for e in range(len(meta["seeds"])):
+        check_episode(z, "", e, meta, pmi_state_dict_h64, meta["steps"])
+
+
 def test_free_running_rollout():
     """fp64 oracle free-runs the whole 200-step episode of g1 from the initial state."""
     z, meta = load_golden("g1_n5m3_raw")
