@@ -306,11 +306,11 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
     constexpr int PPT = 32 / PG;         // pairs per thread in the branch layers (8)
     static_assert(KS >= PPT, "every produced pair needs at least one k-step to hide behind");
 
-    __shared__ float4 lds4[(2 * 3 * PLANE + (2 * 32 * 12 + 2 * NW * 32 + NW * 96) * 4) / 16 + 2];
+    __shared__ float4 lds4[(2 * 3 * PLANE + (2 * 32 * 12 + 2 * NW * 64 + NW * 96) * 4) / 16 + 2];
     unsigned char *aplanes = reinterpret_cast<unsigned char *>(lds4);               // [2 tiles][3 planes][32 pairs][PITCH]
     float *xs = reinterpret_cast<float *>(aplanes + 2 * 3 * PLANE);                // [2 tiles][32 pairs][12]
-    float *part = xs + 2 * 32 * 12;                                                // [2 tiles][NW][32]
-    float *sink = part + 2 * NW * 32;                                              // [NW][96] where non-writer lanes' stores go
+    float *part = xs + 2 * 32 * 12;                                                // [2 tiles][NW][2 column halves][32]
+    float *sink = part + 2 * NW * 64;                                              // [NW][96] where non-writer lanes' stores go
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -338,6 +338,10 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
         for (int s = 0; s < KS; ++s) { asm volatile("" : "+a"(Bh[s])); asm volatile("" : "+a"(Bm[s])); }
     }
     const float bias1 = b1[col], wout = w2[col];
+    f32x16 biasv;                            // fc1's bias as the first MFMA's srcC: no per-tile accumulator initialisation
+#pragma unroll
+    for (int r = 0; r < 16; ++r) biasv[r] = bias1;
+    asm volatile("" : "+a"(biasv));
 
     // Branch layers (PMINet.py:50-55): thread (o2, pg) owns outputs 2 o2 and 2 o2 + 1 of each of the three branches
     // for PPT of the tile's 32 pairs; its 30 folded weights and 6 biases stay in registers.
@@ -459,26 +463,29 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
     // ReLU, fc2 (PMINet.py:60-61) of a finished tile, row r of this wavefront's 16: sum over the block's 32 columns in
     // a fixed butterfly order (bitwise reproducible).  Three pieces, so the main loop can hide them too.
     auto epi_piece = [&](const f32x16 &a, float (&ev)[2], auto ec, float *pc) {
-        // piece e: step e % 6 of rows 2 (e / 6) and 2 (e / 6) + 1 -- two independent chains per piece
+        // piece e: step e % 6 of rows 2 (e / 6) and 2 (e / 6) + 1 -- two independent chains per piece.  The butterfly
+        // stops at the 16-lane row: the two rows of a wavefront half keep separate partials (summed with the column
+        // blocks at the end), which saves the row_bcast step (a v_mov_dpp + v_add pair per row).
         constexpr int e = decltype(ec)::value, st = e % 6;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int r = 2 * (e / 6) + u;
-            if constexpr (st == 0) ev[u] = fmaxf(a[r], 0.0f) * wout;
+            // ReLU on the bit pattern (max as integers: negatives are negative, positives keep their order): one
+            // instruction, where fmaxf on an MFMA result first re-canonicalises it
+            if constexpr (st == 0) ev[u] = __int_as_float(max(__float_as_int(a[r]), 0)) * wout;
             else if constexpr (st == 1) ev[u] = dpp_add<0xB1>(ev[u]);
             else if constexpr (st == 2) ev[u] = dpp_add<0x4E>(ev[u]);
             else if constexpr (st == 3) ev[u] = dpp_add<0x141>(ev[u]);
             else if constexpr (st == 4) ev[u] = dpp_add<0x140>(ev[u]);
             else {
-                ev[u] = dpp_add<0x142, 0xa>(ev[u]);
                 // C/D layout of 32x32 MFMA: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).  Every lane stores: `pc` is
                 // the writer lane's slot base and a private sink for the others (no exec-mask juggling between the MFMAs).
                 pc[(r & 3) + 8 * (r >> 2)] = ev[u];
             }
         }
     };
-    auto partial_base = [&](int buf) {
-        return (lane & 31) == 16 ? part + buf * NW * 32 + w * 32 + 4 * kh : sink + w * 96 + lane;
+    auto partial_base = [&](int buf) {       // writer: lane 0 of each 16-lane row
+        return (lane & 15) == 0 ? part + buf * NW * 64 + w * 64 + ((lane >> 4) & 1) * 32 + 4 * kh : sink + w * 96 + lane;
     };
     // (by the LAST wavefront's first 32 lanes: the first wavefront already carries the input pipeline, and whoever is
     // late holds the others at the tile barrier)
@@ -487,7 +494,7 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
         if (ft >= 0 && ft < 32 && tile * 32 + ft < npairs) {
             float sc = b2;
 #pragma unroll
-            for (int ww = 0; ww < NW; ++ww) sc += pc[ww * 32 + ft];
+            for (int ww = 0; ww < 2 * NW; ++ww) sc += pc[ww * 32 + ft];
             q.scores[tile * 32 + ft] = sc;                      // the pair's own slot: s_ij = s_ji is stored once
         }
     };
@@ -502,9 +509,7 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
         //      terms first), interleaved in program order with the branch layers of the NEXT tile: a wavefront issues
         //      in order and an MFMA holds its SIMD's issue for 8 of its 32 cycles, so the VALU / LDS instructions
         //      placed between two MFMAs of the one accumulation chain run in the shadow of the first
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = bias1;
+        f32x16 acc = biasv;
         const unsigned char *afrag = aplanes + cur * 3 * PLANE + afrag0;
         auto load_a = [&](int s, u32x4 &h, u32x4 &m, u32x4 &l) {
             h = *reinterpret_cast<const u32x4 *>(afrag + 0 * PLANE + s * 32);
@@ -539,7 +544,8 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
                 constexpr int hi = !kTuned ? (slot + 1) * kMicro / nslot : slot < 12 ? (slot / 6) * 13 + pre[slot % 6 + 1] : pre2[slot - 11];
                 const bf16x8 a = as_bf16x8(t == 1 ? fl : (t == 2 || t == 4) ? fm : fh);
                 const bf16x8 bq = as_bf16x8(t == 0 ? Bl[s] : (t == 2 || t == 3) ? Bm[s] : Bh[s]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc, 0, 0, 0);
+                if constexpr (s == 0 && t == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, biasv, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc, 0, 0, 0);
                 if constexpr (t == 0 && s + 1 < KS) load_a(s + 1, gh, gm, gl);
                 static_for<kMicro>([&](auto opc) {
                     if constexpr (decltype(opc)::value >= lo && decltype(opc)::value < hi) micro(P, opc, cur ^ 1, cur ^ 1, pp);
@@ -564,7 +570,7 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
         // also drains the vector-memory counter, i.e. it would wait out the two requests the first wavefront has just
         // made -- a full trip to memory per tile, with every other wavefront parked at the barrier meanwhile.
         UAVTRACK_LDS_BARRIER();
-        if (have_prev) final_sum(tile - G, part + (cur ^ 1) * NW * 32);
+        if (have_prev) final_sum(tile - G, part + (cur ^ 1) * NW * 64);
         accp = acc;
         have_prev = true;
         cur ^= 1;
@@ -576,7 +582,7 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
         __syncthreads();
         // (the last tile of this workgroup: blockIdx.x + G * (its tile count - 1))
         const unsigned last = blockIdx.x + ((ntiles - 1 - blockIdx.x) / G) * G;
-        final_sum(last, part + (cur ^ 1) * NW * 32);
+        final_sum(last, part + (cur ^ 1) * NW * 64);
     }
 }
 
