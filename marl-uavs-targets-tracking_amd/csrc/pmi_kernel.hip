@@ -788,7 +788,10 @@ hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream
     // workgroup per CU.  UAVTRACK_PMI_FP32=1 keeps the fp32-MFMA kernel (A/B measurements, and the wider layers).
     static const bool force_fp32 = [] { const char *s = getenv("UAVTRACK_PMI_FP32"); return s && atoi(s) != 0; }();
     if (q.x6 && !force_fp32) {
-        const int grid6 = env->n_cus > 0 ? env->n_cus : 256;
+        // one workgroup per CU at H = 96 / 128 (3 - 4 wavefronts, one per SIMD); at H = 64 a workgroup is two wavefronts and
+        // 81 KB of LDS, so two of them share a CU and fill its four SIMDs
+        static const int mult64 = [] { const char *e = getenv("UAVTRACK_X6_GRID64"); return e ? atoi(e) : 2; }();
+        const int grid6 = (env->n_cus > 0 ? env->n_cus : 256) * (env->pmi.hidden <= 64 ? mult64 : 1);
         switch (env->pmi.hidden) {
 #define UAVTRACK_PMI_CASE(HH) case HH: hipLaunchKernelGGL(pmi_score_x6_kernel<HH>, dim3(grid6), dim3(2 * HH), 0, stream, q); break;
             UAVTRACK_PMI_CASE(64) UAVTRACK_PMI_CASE(96) UAVTRACK_PMI_CASE(128)
