@@ -42,7 +42,14 @@ for _p in (ROOT, os.path.join(ROOT, "marl-uavs-targets-tracking_amd")):
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_CEILING_GBS = 6290.0
 ROOFLINE_T = 200               # steps per launch of the roofline leg: the reference horizon (main.py:128)
-ROOFLINE_LAUNCHES = 6
+ROOFLINE_LAUNCHES = 10         # timed launches of a roofline leg (median / min / max are reported beside the average)
+# An MI355X that has idled (even 0.5 s) runs its next launches 10-20 % slow and settles over ~20 ms of continuous load
+# (tools/drift.py: 0.60, 0.56, 0.56, 0.61, 0.62, 0.62 ... 0.51 ms over 35 back-to-back launches of the headline rollout,
+# 0.51 flat right after sustained load, whatever the buffers): the power state ramps.  Every measured leg is therefore
+# preceded, without an idle gap, by this much untimed work of the same kind.
+DEVICE_WARM_MS = 60.0
+BF16_MFMA_PEAK_TFLOPS = 2500.0
+FP32_MFMA_PEAK_TFLOPS = 157.3
 
 
 def algorithmic_bytes_per_agent_step(n_uav, m_targets, dim=2, terms=True):
@@ -77,6 +84,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip per-step-launch, saturating-batch and closed-loop legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-device-warmup", action="store_true",
+                    help="skip the untimed device warm-up ahead of the timed region (the GPU then starts from its idle power state)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the roofline legs of BASELINE configs[2] and configs[3]")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only to rehearse "
                     "the multi-rank code path on a single GPU together with UAVTRACK_BENCH_ONE_GPU=1")
     ap.add_argument("--selftest-launcher", action="store_true",
@@ -290,6 +300,7 @@ def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, en
     timed_plan, _ = launch_plan(steps, rollout, horizon, pos)
     # output buffers of every launch shape exist before the clock starts (allocation is not part of a step)
     out = {T: alloc_outputs(args, B, T, device) for T in set(timed_plan) | set(warm_plan)}
+    warm = None if getattr(args, "no_device_warmup", False) else device_warmup(uavtrack, args, B, device)
     obs0 = env.reset(seed=args.seed)
     _, obs0 = run_rollouts(env, actions, warm_plan, 0, out, gather=gather, policy=args.policy, obs=obs0)
     bound = bind_plan(env, actions, timed_plan, pos, out, device) if args.policy == "given" else None
@@ -311,14 +322,45 @@ def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, en
     wall = time.perf_counter() - t0
     info = env.kernel_info()
     env.close()
+    if warm is not None:
+        warm.pop("keep")[0].close()
     return dict(wall_s=wall, launches=launches, steps=steps, geometry=info,
-                timed_plan=timed_plan, warm_plan=warm_plan)
+                timed_plan=timed_plan, warm_plan=warm_plan, device_warmup=warm)
 
 
-def roofline_leg(uavtrack, args, B, device, T=ROOFLINE_T, launches=ROOFLINE_LAUNCHES):
-    """`launches` rollout launches of T steps each (an episode: reset, then one launch), ALL enqueued before the
-    first event is waited on, a HIP event pair on the launch stream around every rollout launch (the resets lie
-    outside the pairs).  One untimed launch first.  Independent of --steps."""
+def device_warmup(uavtrack, args, B, device, warm_ms=DEVICE_WARM_MS):
+    """Untimed: `warm_ms` of back-to-back rollout launches of this workload on a throw-away handle, so that what follows
+    starts at the clocks of a GPU under load, not at those of one waking up (see DEVICE_WARM_MS).  Returns a description."""
+    import torch
+    env = make_env(uavtrack, args, B, device)
+    T = 50
+    g = torch.Generator(device=device).manual_seed(1)
+    actions = torch.randint(0, env.cfg.na_total, (T, B, args.n_uav), dtype=torch.int32, device=device, generator=g)
+    obs = env.reset(seed=1)
+
+    def one(out):
+        if args.policy == "actor":
+            return env.run_actor(T, obs, seed=1, out=out)
+        if args.policy == "greedy":
+            return env.run_greedy(T, seed=1)
+        return env.step_many(actions, out=out)
+    out = one(None)
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); out = one(out); e1.record()
+    torch.cuda.synchronize(device)
+    n = max(2, min(2000, int(warm_ms / max(e0.elapsed_time(e1), 1e-3)) + 1))
+    for _ in range(n):
+        out = one(out)
+    # (no synchronize: the caller's launches queue up behind these; the handle is kept alive until they have run)
+    return dict(ms=warm_ms, launches=n, steps_per_launch=T, keep=(env, actions, out, obs))
+
+
+def roofline_leg(uavtrack, args, B, device, T=ROOFLINE_T, launches=ROOFLINE_LAUNCHES, warm_ms=DEVICE_WARM_MS):
+    """`launches` rollout launches of T steps each (an episode: reset, then one launch), ALL enqueued before the first
+    event is waited on and directly behind >= 3 untimed launches (at least `warm_ms` of them: the device is at its
+    loaded clocks); a HIP event pair on the launch stream around every call (the resets lie outside the pairs), and,
+    inside the library, around every KERNEL of the call (uavtrack_set_profiling).  Independent of --steps."""
     import torch
     env = make_env(uavtrack, args, B, device)
     g = torch.Generator(device=device).manual_seed(args.seed)
@@ -333,7 +375,16 @@ def roofline_leg(uavtrack, args, B, device, T=ROOFLINE_T, launches=ROOFLINE_LAUN
         return env.step_many(actions, out=out)
     one(env.reset(seed=args.seed))
     torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    obs = env.reset(seed=args.seed)
+    e0.record(); one(obs); e1.record()
+    torch.cuda.synchronize(device)
+    untimed = max(3, min(400, int(warm_ms / max(e0.elapsed_time(e1), 1e-3)) + 1))
+    for _ in range(untimed):
+        one(env.reset(seed=args.seed))
+    # (MAAC-R: reading the pair counter waits for the queue -- tens of microseconds of idle, which the clocks do not notice)
     pairs0 = env.pmi_pairs_scored() if args.reward == "pmi" else 0
+    env.set_profiling(True)                       # (a host-side flag)
     pairs = []
     for _ in range(launches):
         obs = env.reset(seed=args.seed)
@@ -344,10 +395,127 @@ def roofline_leg(uavtrack, args, B, device, T=ROOFLINE_T, launches=ROOFLINE_LAUN
         pairs.append((e0, e1))
     torch.cuda.synchronize(device)
     ms = [e0.elapsed_time(e1) for e0, e1 in pairs]
+    kernels = env.profile()
+    env.set_profiling(False)
     pmi_pairs = env.pmi_pairs_scored() - pairs0 if args.reward == "pmi" else 0
     info = env.kernel_info()
     env.close()
-    return dict(T=T, launches=launches, ms=ms, avg_ms=sum(ms) / len(ms), pmi_pairs=pmi_pairs, geometry=info)
+    srt = sorted(ms)
+    return dict(T=T, launches=launches, untimed=untimed, ms=ms, avg_ms=sum(ms) / len(ms), median_ms=srt[len(srt) // 2],
+                min_ms=srt[0], max_ms=srt[-1], pmi_pairs=pmi_pairs, geometry=info, kernels=kernels)
+
+
+def leg_summary(roof):
+    """The per-launch statistics every roofline object carries."""
+    k = {name: {"ms_per_launch": v["ms"] / roof["launches"], "kernel_launches_per_launch": v["launches"] / roof["launches"]}
+         for name, v in roof["kernels"].items() if v["launches"]}
+    return {"steps_per_launch": roof["T"], "launches_timed": roof["launches"], "launches_untimed_before": roof["untimed"],
+            "avg_launch_ms": roof["avg_ms"], "median_launch_ms": roof["median_ms"], "min_launch_ms": roof["min_ms"],
+            "max_launch_ms": roof["max_ms"], "launch_ms": roof["ms"], "kernel_ms": k}
+
+
+def pmi_roofline(args, roof, units_per_launch):
+    """MAAC-R: the roofline object of the pair scorer.  `achieved` divides by the SCORER's own time (library-side HIP
+    events around its launches); the whole-call figures are given beside it."""
+    H = args.pmi_hidden
+    flop_pair = 2.0 * (12 * H + 3 * H * H + H)               # SURVEY 8a-P: 101 632 at H = 128
+    hp = (H + 31) // 32 * 32
+    x6 = 64 <= hp <= 128 and os.environ.get("UAVTRACK_PMI_FP32", "0") in ("", "0")
+    call_s = sum(roof["ms"]) * 1e-3
+    sc = roof["kernels"].get("scorer", {"ms": 0.0, "launches": 0})
+    scorer_s = sc["ms"] * 1e-3 if sc["launches"] else call_s
+    pairs = roof["pmi_pairs"]
+    tf_call = pairs * flop_pair / call_s / 1e12
+    tf_scorer = pairs * flop_pair / scorer_s / 1e12
+    common = {
+        "traffic": None, "flop_per_pair": flop_pair, "pairs_scored": pairs,
+        "pairs_per_agent_step": pairs / (units_per_launch * roof["launches"]),
+        "timing": "library-side HIP events on the launch stream around every scorer launch of the fixed leg "
+                  "(uavtrack_set_profiling); whole_call_* divide by the events around the uavtrack_step_many calls instead "
+                  "(rollout + scorer + mix + episode sums of every chunk)",
+        "scorer_ms_per_launch": scorer_s * 1e3 / roof["launches"],
+        "fp32_equivalent_tflops": tf_scorer, "fp32_equivalent_over_fp32_mfma_peak": tf_scorer / FP32_MFMA_PEAK_TFLOPS,
+        "whole_call_fp32_equivalent_tflops": tf_call,
+        **leg_summary(roof),
+    }
+    if x6:
+        # pmi_score_x6_kernel: the 3H x H layer as SIX bf16 MFMAs per fp32 product (three-way bf16 split, fp32
+        # accuracy).  The roof that bounds it is the bf16 matrix rate; `achieved` counts the bf16 flops the
+        # matrix cores really execute (6 x 2 x 3H x H per pair), not the fp32-equivalent work.
+        executed = pairs * 6.0 * 2.0 * 3 * hp * hp
+        return {
+            "bound": "mfma", "kernel": f"pmi_score_x6_kernel<{hp}>", "achieved": executed / scorer_s / 1e12,
+            "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": executed / scorer_s / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+            "whole_call_frac": executed / call_s / 1e12 / BF16_MFMA_PEAK_TFLOPS, **common,
+            "peak_note": "bf16 MFMA dense peak (~2.5 PFLOP/s, MI355X_MICROARCH.md); executed flops = 6 bf16 MFMAs per "
+                         "fp32 product; fp32_equivalent_* restate the same time as plain fp32 work against the 157.3 "
+                         "TFLOP/s fp32-MFMA peak the round-1 scorer was bounded by",
+        }
+    return {
+        "bound": "mfma", "kernel": f"pmi_score_kernel<{hp}>", "achieved": tf_scorer, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": tf_scorer / FP32_MFMA_PEAK_TFLOPS, "whole_call_frac": tf_call / FP32_MFMA_PEAK_TFLOPS, **common,
+        "peak_note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak = fp32 vector peak, MI355X_MICROARCH.md",
+    }
+
+
+def hbm_roofline(args, roof, B, N, M):
+    """The HBM roofline object of a rollout_kernel launch shape (SURVEY 8d algorithmic bytes)."""
+    bytes_unit = algorithmic_bytes_per_agent_step(N, M, args.dim)
+    units = B * N * roof["T"]
+    rk = roof["kernels"].get("rollout", {"ms": 0.0, "launches": 0})
+    # the rollout kernel's own time (library-side events); the call-level events agree within a few microseconds
+    kern_ms = rk["ms"] / rk["launches"] if rk["launches"] else roof["avg_ms"]
+    achieved = bytes_unit * units / (kern_ms * 1e-3) / 1e9
+    traffic, src = lookup_traffic(B, N, M, roof["T"], args)
+    r = {
+        "bound": "hbm", "kernel": "rollout_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
+        "traffic": traffic, "algorithmic_bytes_per_agent_step": bytes_unit, "agent_steps_per_launch": units,
+        "kernel_avg_ms": kern_ms,
+        "frac_at_median_call": bytes_unit * units / (roof["median_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "frac_at_slowest_call": bytes_unit * units / (roof["max_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "timing": f"fixed leg, independent of --steps: {roof['launches']} launches of {roof['T']} steps (reset before each) directly "
+                  f"behind {roof['untimed']} untimed ones, all enqueued before the first event is waited on; HIP events on the "
+                  "launch stream around the kernel (library side) and around every call",
+        **leg_summary(roof),
+    }
+    if src:
+        r["traffic_source"] = src
+    return r
+
+
+def other_configs(uavtrack, args, device):
+    """The other two single-GPU BASELINE configurations on the default line: a fixed roofline leg each for configs[2]
+    (4096 x 20 x 10 MAAC-R, PMI at H = 128 = configs/MAAC-R.yaml:39 and at H = 64 = PMINet.py:21) and configs[3]
+    (8192 x 50 x 25, 3-D).  ~2 s of GPU time."""
+    import copy
+    out = []
+    for name, over in (("configs[2] MAAC-R, PMI hidden 128", dict(reward="pmi", pmi_hidden=128, envs=4096, n_uav=20, m_targets=10, dim=2)),
+                       ("configs[2] MAAC-R, PMI hidden 64 (PMINetwork's default)", dict(reward="pmi", pmi_hidden=64, envs=4096, n_uav=20, m_targets=10, dim=2)),
+                       ("configs[3] 3-D kinematics", dict(reward="raw", envs=8192, n_uav=50, m_targets=25, dim=3))):
+        a = copy.copy(args)
+        for k, v in over.items():
+            setattr(a, k, v)
+        a.policy, a.box = "given", 2000.0
+        a.cooperative = 0.0 if a.reward == "raw" else 0.3
+        B, N, M = a.envs, a.n_uav, a.m_targets
+        roof = roofline_leg(uavtrack, a, B, device)
+        units = B * N * roof["T"]
+        ent = {"config": name,
+               "workload": f"{B} envs x {N} UAVs x {M} targets, {a.dim}-D, "
+                           + (f"MAAC-R reciprocal (PMI H={a.pmi_hidden}) reward" if a.reward == "pmi" else "MAAC tracking reward"),
+               "agent_steps_per_s": units / (roof["avg_ms"] * 1e-3), "agent_steps_per_s_at_median": units / (roof["median_ms"] * 1e-3),
+               "geometry": roof["geometry"]}
+        hb = hbm_roofline(a, roof, B, N, M)
+        if a.reward == "pmi":
+            ent["roofline"] = pmi_roofline(a, roof, units)
+            ent["roofline_hbm_all_kernels"] = {k: hb[k] for k in ("bound", "achieved", "peak", "unit", "frac", "algorithmic_bytes_per_agent_step")}
+            ent["roofline_hbm_all_kernels"]["achieved"] = hb["algorithmic_bytes_per_agent_step"] * units / (roof["avg_ms"] * 1e-3) / 1e9
+            ent["roofline_hbm_all_kernels"]["frac"] = ent["roofline_hbm_all_kernels"]["achieved"] / HBM_PEAK_GBS
+        else:
+            ent["roofline"] = hb
+        out.append(ent)
+    return out
 
 
 def host_cores():
@@ -405,13 +573,13 @@ def cpu_baseline(args, seconds):
 def lookup_traffic(B, N, M, T, args):
     """HBM bytes per launch from the committed PMC profile of exactly this launch shape, else None."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
-    if args.reward != "raw" or args.dim != 2 or args.policy != "given" or not os.path.exists(path):
+    if args.reward != "raw" or args.policy != "given" or not os.path.exists(path):
         return None, None
     try:
         tr = json.load(open(path))
     except Exception:
         return None, None
-    ent = tr.get(f"{B}x{N}x{M}_T{T}")
+    ent = tr.get(f"{B}x{N}x{M}_T{T}" + ("_3d" if args.dim == 3 else ""))
     if not ent:
         return None, None
     return ent["hbm_bytes_per_launch"], ent.get("source", "profiles/")
@@ -433,6 +601,19 @@ def extras(uavtrack, args, B, device, bytes_unit):
         "ms_per_step_all_runs": [r["wall_s"] * 1e3 / k for r in runs],
         "note": "uavtrack_step eager from Python/ctypes, best of three 400-step runs; host-launch bound",
     }
+    # the T = 1 kernel's own duration (library-side HIP events around each launch; an event pair adds ~1-2 us of its own)
+    env = make_env(uavtrack, args, B, device)
+    g = torch.Generator(device=device).manual_seed(3)
+    acts = torch.randint(0, env.cfg.na_total, (B, N), dtype=torch.int32, device=device, generator=g)
+    env.reset(seed=args.seed)
+    for _ in range(300):
+        env.step(acts)
+    env.set_profiling(True)
+    for _ in range(200):
+        env.step(acts)
+    pr = env.profile()["rollout"]
+    env.close()
+    out["per_step_launch"]["kernel_us_per_step"] = pr["ms"] * 1e3 / max(pr["launches"], 1)
     # a batch that fills the chip (SURVEY 8d 'bandwidth-saturating batch'), measured like the roofline leg
     # (200-step launches like the headline leg when the 17 GB of outputs fit comfortably; 50-step launches otherwise --
     # they carry the kernel's start-up cost four times as often and read ~15 % lower)
@@ -548,8 +729,6 @@ def worker(args):
         value = world * B * N * args.steps / wall_s
         roof = roofline_leg(uavtrack, args, B, device)
         units_per_launch = B * N * roof["T"]
-        achieved = bytes_unit * units_per_launch / (roof["avg_ms"] * 1e-3) / 1e9
-        traffic, traffic_src = lookup_traffic(B, N, M, roof["T"], args)
         fn = {"given": "uavtrack_step_many", "greedy": "uavtrack_run_greedy", "actor": "uavtrack_run_actor"}[args.policy]
         if args.rollout == 1 and args.policy == "given":
             fn = "uavtrack_step"
@@ -589,70 +768,29 @@ def worker(args):
                 "parallelism": (f"env-sharded x{world}, {'RCCL' if args.backend == 'nccl' else args.backend} "
                                 f"all-gather of ep_sums per rollout, asynchronous (overlaps the next rollout)") if world > 1 else "1 GPU",
                 "geometry": res["geometry"],
+                "device_warmup": ("none (--no-device-warmup): the timed region starts from the GPU's idle power state" if res["device_warmup"] is None else
+                                  f"{res['device_warmup']['launches']} untimed {res['device_warmup']['steps_per_launch']}-step launches of this workload on a "
+                                  f"separate handle (~{res['device_warmup']['ms']:.0f} ms) directly ahead of the {args.warmup} warm-up steps: an MI355X "
+                                  "that has idled runs its next ~20 ms of launches 10-20 % slow (tools/drift.py)"),
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "rollout_kernel",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
-                "traffic": traffic,
-                "algorithmic_bytes_per_agent_step": bytes_unit,
-                "steps_per_launch": roof["T"],
-                "agent_steps_per_launch": units_per_launch,
-                "avg_launch_ms": roof["avg_ms"],
-                "launch_ms": roof["ms"],
-                "launches_timed": roof["launches"],
-                "timing": f"fixed leg, independent of --steps: {roof['launches']} launches of {roof['T']} steps (reset before each), all "
-                          "enqueued before the first event is waited on; HIP events on the launch stream around every launch",
-            },
+            "roofline": hbm_roofline(args, roof, B, N, M),
         }
-        if traffic_src:
-            line["roofline"]["traffic_source"] = traffic_src
         if args.reward == "pmi":
-            H = args.pmi_hidden
-            flop_pair = 2.0 * (12 * H + 3 * H * H + H)               # 101 632 at H = 128
-            tf = roof["pmi_pairs"] * flop_pair / (sum(roof["ms"]) * 1e-3) / 1e12
             line["roofline_hbm_all_kernels"] = line["roofline"]
-            hp = (H + 31) // 32 * 32
-            x6 = 64 <= hp <= 128 and os.environ.get("UAVTRACK_PMI_FP32", "0") in ("", "0")
-            secs = sum(roof["ms"]) * 1e-3
-            common = {
-                "traffic": None, "flop_per_pair": flop_pair, "pairs_scored": roof["pmi_pairs"],
-                "pairs_per_agent_step": roof["pmi_pairs"] / (units_per_launch * roof["launches"]),
-                "steps_per_launch": roof["T"], "launches_timed": roof["launches"], "avg_launch_ms": roof["avg_ms"],
-                "timing": "HIP events around every uavtrack_step_many call of the fixed leg (all kernels of each chunk: a "
-                          "lower bound for the scorer alone; the per-kernel split is in profiles/)",
-                "fp32_equivalent_tflops": tf, "fp32_equivalent_over_fp32_mfma_peak": tf / 157.3,
-            }
-            if x6:
-                # pmi_score_x6_kernel: the 3H x H layer as SIX bf16 MFMAs per fp32 product (three-way bf16 split, fp32
-                # accuracy).  The roof that bounds it is the bf16 matrix rate; `achieved` counts the bf16 flops the
-                # matrix cores really execute (6 x 2 x 3H x H per pair), not the fp32-equivalent work.
-                executed = roof["pmi_pairs"] * 6.0 * 2.0 * 3 * hp * hp / secs / 1e12
-                line["roofline"] = {
-                    "bound": "mfma", "kernel": "pmi_score_x6_kernel", "achieved": executed, "peak": 2500.0, "unit": "TFLOP/s",
-                    "frac": executed / 2500.0, **common,
-                    "peak_note": "bf16 MFMA dense peak (~2.5 PFLOP/s, MI355X_MICROARCH.md); executed flops = 6 bf16 MFMAs per "
-                                 "fp32 product; fp32_equivalent_* restate the same time as plain fp32 work against the 157.3 "
-                                 "TFLOP/s fp32-MFMA peak the round-1 scorer was bounded by",
-                }
-            else:
-                line["roofline"] = {
-                    "bound": "mfma", "kernel": "pmi_score_kernel", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s",
-                    "frac": tf / 157.3, **common,
-                    "peak_note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak = fp32 vector peak, MI355X_MICROARCH.md",
-                }
+            line["roofline"] = pmi_roofline(args, roof, units_per_launch)
         if args.policy == "actor":
             # the actor adds 2*(12*H + H*16*tiles) fp32 MFMA flops per agent-step (actions padded to 16-row tiles: 1 in 2-D, 3 in 3-D)
             Hp = (args.actor_hidden + 15) // 16 * 16
             rl = line["roofline"]
             rl["actor_mfma_flop_per_agent_step"] = 2 * (12 * Hp + Hp * 16 * (3 if args.dim == 3 else 1))
             rl["actor_mfma_tflops"] = rl["actor_mfma_flop_per_agent_step"] * units_per_launch / (roof["avg_ms"] * 1e-3) / 1e12
+            rl["actor_mfma_frac_of_fp32_mfma_peak"] = rl["actor_mfma_tflops"] / FP32_MFMA_PEAK_TFLOPS
             rl["note"] = ("closed-loop launch: environment step (HBM roofline above) plus the policy network on the "
                           "fp32 matrix cores (peak 157.3 TFLOP/s); both figures are over the whole launch")
+        default_workload = (world == 1 and args.reward == "raw" and args.policy == "given" and args.dim == 2 and args.box == 2000.0
+                            and (B, N, M) == (4096, 20, 10))
+        if default_workload and not args.no_other_configs:
+            line["other_configs"] = other_configs(uavtrack, args, device)
         if world == 1 and not args.no_extras and args.reward != "pmi" and args.policy == "given":
             line.update(extras(uavtrack, args, B, device, bytes_unit))
         if world == 1 and not args.no_cpu_baseline:

@@ -113,6 +113,14 @@ int uavtrack_get_state(uavtrack_env *env,
                        float *tx, float *ty, float *tz, float *th,
                        int32_t *step_count, void *stream);
 
+/* The rest of the checkpoint: episode [B] int32 (device pointer) = the number of each environment's last reset
+ * (uavtrack_reset's `episode` argument, advanced by every automatic reset).  It keys the Philox counter of the next
+ * automatic reset (uavtrack_step_many_autoreset), so a handle restored with uavtrack_set_state + uavtrack_set_episodes
+ * resets into the same states as the run the checkpoint was taken from.  (A separate pair of entry points: the
+ * signatures of uavtrack_set_state / uavtrack_get_state stay as they are.) */
+int uavtrack_set_episodes(uavtrack_env *env, const int32_t *episode, void *stream);
+int uavtrack_get_episodes(uavtrack_env *env, int32_t *episode, void *stream);
+
 /* Replaces the `pmi` argument of Environment.step (environment.py:120;
  * PMINetwork.inference PMINet.py:64-72, eval mode).  `folded` is a HOST
  * pointer to the BatchNorm-folded fp32 blob, layout (H = hidden):
@@ -121,6 +129,13 @@ int uavtrack_get_state(uavtrack_env *env,
  * equal 12H + 3H + 3H*H + H + H + 1.  folded == NULL disables PMI. */
 int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_floats,
                              int32_t hidden, void *stream);
+
+/* Replaces PMINetwork.inference (PMINet.py:64-72: eval mode, no grad) on a batch: x [n][12] (device; row k is what
+ * uav.py:281 builds, la_i * la_j) -> scores [n] (device), with the weights of uavtrack_set_pmi_weights and on the very
+ * kernels that score the neighbour pairs of a MAAC-R step (bf16 x 6 or fp32 MFMA by width) -- the network alone, for
+ * callers that hold pair inputs of their own and for accuracy tests of the scorer.  Stream-ordered; must not run
+ * concurrently with a MAAC-R step of the same handle.  (The pairs it scores are included in uavtrack_pmi_pairs_scored.) */
+int uavtrack_pmi_inference(uavtrack_env *env, const float *x, int64_t n, float *scores, void *stream);
 
 /* Replaces Environment.step (environment.py:120-164) for the whole batch.
  *   actions [B][N] int32 in [0, na*nc)      (train.py:173-176 action_list)
@@ -229,6 +244,18 @@ int uavtrack_set_target_trace(uavtrack_env *env, float *tpos, int32_t capacity_s
 /* MAAC-R accounting for reports: out[0] = neighbour pairs scored by the PMI network since
  * the weights were set (each unordered pair once per step).  Synchronises `stream`. */
 int uavtrack_pmi_pairs_scored(uavtrack_env *env, uint64_t *out, void *stream);
+
+/* Measurement hook (bench.py's roofline legs): with profiling on, every kernel launch of the stepping entry points is
+ * bracketed by a HIP event pair on the launch stream.  uavtrack_get_profile synchronises `stream`, adds the elapsed
+ * milliseconds up per kernel class into ms[UAVTRACK_PROF_CLASSES] and the launch counts into launches[...] (either may
+ * be NULL), and forgets the recorded pairs.  Off by default: no events, no cost. */
+enum { UAVTRACK_PROF_ROLLOUT = 0,   /* rollout_kernel: the fused environment step(s) */
+       UAVTRACK_PROF_SCORER  = 1,   /* MAAC-R: pmi_score_x6_kernel / pmi_score_kernel */
+       UAVTRACK_PROF_MIX     = 2,   /* MAAC-R: pmi_mix_kernel (softmax mix + final clip) */
+       UAVTRACK_PROF_EPSUMS  = 3,   /* MAAC-R: ep_sums_kernel */
+       UAVTRACK_PROF_CLASSES = 4 };
+int uavtrack_set_profiling(uavtrack_env *env, int32_t on);
+int uavtrack_get_profile(uavtrack_env *env, double *ms, int64_t *launches, void *stream);
 
 /* Launch geometry of the step kernel, for reports: out[0] = workgroup size,
  * out[1] = envs per workgroup, out[2] = workgroups, out[3] = LDS bytes per

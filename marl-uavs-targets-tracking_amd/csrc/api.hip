@@ -69,10 +69,33 @@ hipError_t dmalloc(T **p, size_t n)
     return hipMalloc(reinterpret_cast<void **>(p), (n ? n : 1) * sizeof(T));
 }
 
+void drop_profile(uavtrack_env *env)
+{
+    for (auto &r : env->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    env->prof.clear();
+}
+
+// One kernel launch of a stepping entry point, bracketed by an event pair when profiling is on (uavtrack_set_profiling).
+template <typename F>
+hipError_t timed_launch(uavtrack_env *env, int cls, hipStream_t st, F &&launch)
+{
+    if (!env->profiling) return launch();
+    uavtrack_env::ProfRec r{cls, nullptr, nullptr};
+    hipError_t e = hipEventCreate(&r.a);
+    if (e == hipSuccess) e = hipEventCreate(&r.b);
+    if (e == hipSuccess) e = hipEventRecord(r.a, st);
+    if (e != hipSuccess) return e;
+    e = launch();
+    if (e == hipSuccess) e = hipEventRecord(r.b, st);
+    env->prof.push_back(r);
+    return e;
+}
+
 void free_state(uavtrack_env *env)
 {
+    drop_profile(env);
     void *ptrs[] = {env->slab, env->pmi.blob, env->actor_w, env->pairs, env->pair_count, env->pair_total, env->scores, env->nbrec,
-                    env->obs_tmp, env->terms_tmp, env->covered_tmp};
+                    env->obs_tmp, env->terms_tmp, env->covered_tmp, env->inf_obs, env->inf_pairs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -94,10 +117,12 @@ int validate(const uavtrack_config &c)
     if (c.horizon < 0) return fail("horizon must be >= 0");
     if (!(c.dc > 0) || !(c.dp > 0) || !(c.u_v_max > 0) || !(c.dt > 0)) return fail("dc, dp, u_v_max, dt must be > 0");
     // the step kernel addresses a step's outputs as uniform base + 32-bit lane offset (largest row: obs, 48 B per agent)
-    if ((int64_t)c.n_envs * c.n_uav * UAVTRACK_OBS_DIM * 4 >= ((int64_t)1 << 32) ||
-        (int64_t)c.n_envs * c.m_targets >= ((int64_t)1 << 30))
+    if ((int64_t)c.n_envs * c.n_uav * UAVTRACK_OBS_DIM * 4 >= ((int64_t)1 << 32))
         return fail("batch too large: n_envs * n_uav must stay below %lld agents per GPU (got %lld)",
                     (long long)(((int64_t)1 << 32) / (UAVTRACK_OBS_DIM * 4)), (long long)c.n_envs * c.n_uav);
+    if ((int64_t)c.n_envs * c.m_targets >= ((int64_t)1 << 30))
+        return fail("batch too large: n_envs * m_targets must stay below %lld targets per GPU (got %lld)",
+                    (long long)((int64_t)1 << 30), (long long)c.n_envs * c.m_targets);
     return 0;
 }
 
@@ -338,6 +363,26 @@ int uavtrack_get_state(uavtrack_env *env, float *ux, float *uy, float *uz, float
     return 0;
 }
 
+int uavtrack_set_episodes(uavtrack_env *env, const int32_t *episode, void *stream)
+{
+    if (!env) return fail("uavtrack_set_episodes: null handle");
+    if (!episode) return fail("uavtrack_set_episodes: episode is null");
+    ON_DEVICE(env->cfg.device_id);
+    HIP_TRY(hipMemcpyAsync(env->state.episode, episode, (size_t)env->cfg.n_envs * 4, hipMemcpyDeviceToDevice,
+                           static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int uavtrack_get_episodes(uavtrack_env *env, int32_t *episode, void *stream)
+{
+    if (!env) return fail("uavtrack_get_episodes: null handle");
+    if (!episode) return fail("uavtrack_get_episodes: episode is null");
+    ON_DEVICE(env->cfg.device_id);
+    HIP_TRY(hipMemcpyAsync(episode, env->state.episode, (size_t)env->cfg.n_envs * 4, hipMemcpyDeviceToDevice,
+                           static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_floats, int32_t hidden, void *stream)
 {
     if (!env) return fail("uavtrack_set_pmi_weights: null handle");
@@ -402,6 +447,32 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
     return 0;
 }
 
+int uavtrack_pmi_inference(uavtrack_env *env, const float *x, int64_t n, float *scores, void *stream)
+{
+    if (!env) return fail("uavtrack_pmi_inference: null handle");
+    if (n < 0 || n >= ((int64_t)1 << 31)) return fail("uavtrack_pmi_inference: n must be in [0, 2^31) (got %lld)", (long long)n);
+    if (n == 0) return 0;
+    if (!x || !scores) return fail("uavtrack_pmi_inference: x and scores must not be null");
+    if (!env->pmi.blob) return fail("uavtrack_pmi_inference: needs uavtrack_set_pmi_weights first");
+    ON_DEVICE(env->cfg.device_id);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if ((size_t)n > env->inf_cap) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (env->inf_obs) (void)hipFree(env->inf_obs);
+        if (env->inf_pairs) (void)hipFree(env->inf_pairs);
+        env->inf_obs = nullptr; env->inf_pairs = nullptr; env->inf_cap = 0;
+        HIP_TRY(dmalloc(&env->inf_obs, (size_t)n * 2 * UAVTRACK_OBS_DIM));
+        HIP_TRY(dmalloc(&env->inf_pairs, (size_t)n));
+        env->inf_cap = (size_t)n;
+    }
+    // the scorer reads its pair count from the device counter the rollout kernel normally fills (zero between calls)
+    HIP_TRY(launch_pmi_inference_prep(x, env->inf_obs, env->inf_pairs, (unsigned)n, st));
+    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(env->pair_count), (int)n, 1, st));
+    HIP_TRY(launch_pmi_score(env, env->inf_obs, st, env->inf_pairs, scores, 2));
+    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(env->pair_count), 0, 1, st));
+    return 0;
+}
+
 // Where a rollout's actions come from: the caller's tensor, or the in-kernel actor (uavtrack_run_actor).
 struct PolicyArgs {
     bool auto_reset = false;           // uavtrack_step_many_autoreset: reset seed
@@ -443,7 +514,7 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
     }
     if (env->cfg.reward_mode != UAVTRACK_REWARD_PMI) {
         p.T = T;
-        HIP_TRY(launch_rollout(env, p, st, pol.policy));
+        HIP_TRY(timed_launch(env, UAVTRACK_PROF_ROLLOUT, st, [&] { return launch_rollout(env, p, st, pol.policy); }));
         return 0;
     }
     // MAAC-R.  Rewards never feed back into the dynamics, so scoring is deferred: a chunk of steps is
@@ -473,14 +544,14 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
         p.covered = covered_t;
         p.done = done ? done + (size_t)t0 * c.n_envs : nullptr;
         p.tpos = env->tpos ? env->tpos + (size_t)t0 * c.n_envs * c.m_targets : nullptr;
-        HIP_TRY(launch_rollout(env, p, st, pol.policy));
+        HIP_TRY(timed_launch(env, UAVTRACK_PROF_ROLLOUT, st, [&] { return launch_rollout(env, p, st, pol.policy); }));
         // the actor of the next chunk starts from this chunk's last observation (a lane reads its own row
         // once, at launch start, before it writes anything: the scratch buffer may be reused in place)
         p.obs_in = obs_t + (size_t)(n - 1) * BN * UAVTRACK_OBS_DIM;
-        HIP_TRY(launch_pmi_score(env, obs_t, st));
-        HIP_TRY(launch_pmi_finalize(env, n, reward_t, st));
+        HIP_TRY(timed_launch(env, UAVTRACK_PROF_SCORER, st, [&] { return launch_pmi_score(env, obs_t, st); }));
+        HIP_TRY(timed_launch(env, UAVTRACK_PROF_MIX, st, [&] { return launch_pmi_finalize(env, n, reward_t, st); }));
         if (ep_sums) {
-            HIP_TRY(launch_ep_sums(env, n, reward_t, terms_t, covered_t, ep_sums, add, st));
+            HIP_TRY(timed_launch(env, UAVTRACK_PROF_EPSUMS, st, [&] { return launch_ep_sums(env, n, reward_t, terms_t, covered_t, ep_sums, add, st); }));
             add = true;
         }
     }
@@ -537,7 +608,8 @@ int uavtrack_run_greedy(uavtrack_env *env, int32_t T, uint64_t seed, int32_t *ac
     p.pairs = nullptr; p.pair_count = nullptr; p.ep_accumulate = 0;
     p.env_offset = env->cfg.env_offset;
     p.greedy_k0 = (uint32_t)seed; p.greedy_k1 = (uint32_t)(seed >> 32);
-    HIP_TRY(launch_rollout(env, p, static_cast<hipStream_t>(stream), kPolicyGreedy));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(timed_launch(env, UAVTRACK_PROF_ROLLOUT, st, [&] { return launch_rollout(env, p, st, kPolicyGreedy); }));
     return 0;
 }
 
@@ -640,6 +712,35 @@ int uavtrack_pmi_pairs_scored(uavtrack_env *env, uint64_t *out, void *stream)
     HIP_TRY(hipMemcpyAsync(&v, env->pair_total, sizeof v, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     *out = v;
+    return 0;
+}
+
+int uavtrack_set_profiling(uavtrack_env *env, int32_t on)
+{
+    if (!env) return fail("uavtrack_set_profiling: null handle");
+    ON_DEVICE(env->cfg.device_id);
+    drop_profile(env);
+    env->profiling = on != 0;
+    return 0;
+}
+
+int uavtrack_get_profile(uavtrack_env *env, double *ms, int64_t *launches, void *stream)
+{
+    if (!env) return fail("uavtrack_get_profile: null handle");
+    ON_DEVICE(env->cfg.device_id);
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    for (int k = 0; k < UAVTRACK_PROF_CLASSES; ++k) {
+        if (ms) ms[k] = 0.0;
+        if (launches) launches[k] = 0;
+    }
+    for (auto &r : env->prof) {
+        float t = 0.0f;
+        if (r.a && r.b && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess && r.cls >= 0 && r.cls < UAVTRACK_PROF_CLASSES) {
+            if (ms) ms[r.cls] += (double)t;
+            if (launches) launches[r.cls] += 1;
+        }
+    }
+    drop_profile(env);
     return 0;
 }
 

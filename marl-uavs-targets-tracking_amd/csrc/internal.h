@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "uavtrack.h"
 
 namespace uavtrack {
@@ -145,6 +147,15 @@ struct uavtrack_env {
     float2 *tpos = nullptr;           // caller's target-trace buffer (not owned), capacity in steps
     int32_t tpos_steps = 0;
     int32_t *covered_tmp = nullptr;   // [steps][B] coverage counts for ep_sums when the caller passes covered = NULL
+    // uavtrack_set_profiling: a HIP event pair on the launch stream around every kernel launch of the stepping entry points,
+    // by kernel class (UAVTRACK_PROF_*); read and cleared by uavtrack_get_profile
+    struct ProfRec { int cls; hipEvent_t a, b; };
+    bool profiling = false;
+    std::vector<ProfRec> prof;
+    // uavtrack_pmi_inference scratch (grow-only): [2 n][12] scorer inputs and the n pair records
+    float *inf_obs = nullptr;
+    uint2 *inf_pairs = nullptr;
+    size_t inf_cap = 0;
 };
 
 namespace uavtrack {
@@ -163,7 +174,10 @@ constexpr int kPmiX6MaxHidden = 128;                // widest layer whose three 
 constexpr int kPmiX6MinHidden = 64;                 // (narrower layers have fewer k-steps than the producer has pairs to hide)
 inline size_t pmi_x6_floats(int hp) { return hp >= kPmiX6MinHidden && hp <= kPmiX6MaxHidden ? (size_t)3 * hp * hp * 3 / 2 : 0; }   // 3 planes x 2 B
 void pack_pmi_x6(const float *abi_blob, uint16_t *planes, int hidden);
-hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream_t stream);
+// (pairs / scores / n_uav default to the handle's MAAC-R scratch and swarm size; uavtrack_pmi_inference passes its own)
+hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream_t stream, const uint2 *pairs = nullptr,
+                            float *scores = nullptr, int n_uav = 0);
+hipError_t launch_pmi_inference_prep(const float *x, float *obs2, uint2 *pairs, unsigned n, hipStream_t stream);
 hipError_t launch_pmi_finalize(const uavtrack_env *env, int steps, float *reward, hipStream_t stream);
 hipError_t launch_ep_sums(const uavtrack_env *env, int steps, const float *reward, const float *terms,
                           const int32_t *covered, float *ep_sums, bool add, hipStream_t stream);

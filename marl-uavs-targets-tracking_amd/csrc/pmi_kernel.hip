@@ -307,6 +307,8 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
     static_assert(KS >= PPT, "every produced pair needs at least one k-step to hide behind");
 
     __shared__ float4 lds4[(2 * 3 * PLANE + (2 * 32 * 12 + 2 * NW * 64 + NW * 96) * 4) / 16 + 2];
+    // H = 64 runs two workgroups per CU (launch_pmi_score): both must fit the CU's 160 KiB of LDS
+    static_assert(H != 64 || 2 * sizeof(lds4) <= 160 * 1024, "two H = 64 workgroups no longer share a CU: shrink xs / part / sink");
     unsigned char *aplanes = reinterpret_cast<unsigned char *>(lds4);               // [2 tiles][3 planes][32 pairs][PITCH]
     float *xs = reinterpret_cast<float *>(aplanes + 2 * 3 * PLANE);                // [2 tiles][32 pairs][12]
     float *part = xs + 2 * 32 * 12;                                                // [2 tiles][NW][2 column halves][32]
@@ -767,17 +769,40 @@ void pack_pmi_x6(const float *abi_blob, uint16_t *planes, int H)
                 }
 }
 
-hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream_t stream)
+// x [n][12] -> the scorer's inputs for n stand-alone evaluations (uavtrack_pmi_inference): "environments" of two UAVs
+// whose observations are x_k and a row of ones (x * 1 = x exactly), and the pair (0, 1) of each.
+__global__ void __launch_bounds__(256) pmi_inference_prep_kernel(const float4 *__restrict__ x, float4 *__restrict__ obs2,
+                                                                 uint2 *__restrict__ pairs, unsigned n)
+{
+    const unsigned k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= n) return;
+    const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        obs2[(size_t)k * 6 + v] = x[(size_t)k * 3 + v];
+        obs2[(size_t)k * 6 + 3 + v] = one;
+    }
+    pairs[k] = make_uint2(2u * k, 1u);
+}
+
+hipError_t launch_pmi_inference_prep(const float *x, float *obs2, uint2 *pairs, unsigned n, hipStream_t stream)
+{
+    hipLaunchKernelGGL(pmi_inference_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, stream,
+                       reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(obs2), pairs, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream_t stream, const uint2 *pairs, float *scores, int n_uav)
 {
     PmiParams q;
     q.blob = env->pmi.blob;
     q.x6 = env->pmi.x6;
     q.obs = obs;
-    q.pairs = env->pairs;
+    q.pairs = pairs ? pairs : env->pairs;
     q.pair_count = env->pair_count;
-    q.scores = env->scores;
+    q.scores = scores ? scores : env->scores;
     q.pair_total = env->pair_total;
-    q.N = env->cfg.n_uav;
+    q.N = n_uav > 0 ? n_uav : env->cfg.n_uav;
     // persistent workgroups grid-striding over 32-pair tiles, two per CU: __launch_bounds__(2H, 2) holds
     // the kernel to 256 registers per lane (a few spills at H = 128) so that one workgroup's branch
     // layers / epilogue overlap the other's MFMAs -- measured +12 % over one 296-register workgroup
@@ -790,7 +815,11 @@ hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream
     if (q.x6 && !force_fp32) {
         // one workgroup per CU at H = 96 / 128 (3 - 4 wavefronts, one per SIMD); at H = 64 a workgroup is two wavefronts and
         // 81 KB of LDS, so two of them share a CU and fill its four SIMDs
-        static const int mult64 = [] { const char *e = getenv("UAVTRACK_X6_GRID64"); return e ? atoi(e) : 2; }();
+        static const int mult64 = [] {
+            const char *e = getenv("UAVTRACK_X6_GRID64");
+            const int v = e ? atoi(e) : 2;
+            return v < 1 ? 1 : (v > 4 ? 4 : v);          // (experiments; anything unparsable or out of range is clamped)
+        }();
         const int grid6 = (env->n_cus > 0 ? env->n_cus : 256) * (env->pmi.hidden <= 64 ? mult64 : 1);
         switch (env->pmi.hidden) {
 #define UAVTRACK_PMI_CASE(HH) case HH: hipLaunchKernelGGL(pmi_score_x6_kernel<HH>, dim3(grid6), dim3(2 * HH), 0, stream, q); break;

@@ -36,6 +36,7 @@ class UavtrackConfig(C.Structure):
 
 
 ACTOR_SAMPLE, ACTOR_ARGMAX = 0, 1   # enum in include/uavtrack.h
+PROF_CLASSES = ("rollout", "scorer", "mix", "ep_sums")   # UAVTRACK_PROF_* in include/uavtrack.h
 
 # name -> (restype, argtypes); every symbol declared in include/uavtrack.h
 SIGNATURES = {
@@ -46,7 +47,10 @@ SIGNATURES = {
     "uavtrack_reset": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),
     "uavtrack_set_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 10 + [C.c_void_p]),
     "uavtrack_get_state": (C.c_int, [C.c_void_p] + [C.c_void_p] * 10 + [C.c_void_p]),
+    "uavtrack_set_episodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "uavtrack_get_episodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "uavtrack_set_pmi_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
+    "uavtrack_pmi_inference": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "uavtrack_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.c_void_p]),
     "uavtrack_step_accumulate": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.c_void_p]),
     "uavtrack_step_many": (C.c_int, [C.c_void_p, C.c_int32] + [C.c_void_p] * 7 + [C.c_void_p]),
@@ -58,6 +62,8 @@ SIGNATURES = {
     "uavtrack_run_actor": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.c_int32] + [C.c_void_p] * 8 + [C.c_void_p]),
     "uavtrack_set_target_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "uavtrack_pmi_pairs_scored": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),
+    "uavtrack_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
+    "uavtrack_get_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_void_p]),
     "uavtrack_kernel_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
 }
 

@@ -43,6 +43,7 @@ class BatchedUavEnv:
         self._h = handle
         self.info: Dict[str, torch.Tensor] = {}
         self._episode = 0
+        self._trace: Optional[torch.Tensor] = None    # the installed target-trace buffer (kept alive: the library holds its raw pointer)
 
     # -- plumbing ---------------------------------------------------------------------
     @property
@@ -148,10 +149,12 @@ class BatchedUavEnv:
         call until replaced; None switches the output off."""
         if buf is None:
             _lib.check(self._lib.uavtrack_set_target_trace(self._h, None, 0), "uavtrack_set_target_trace")
+            self._trace = None
             return
         if buf.dim() != 4 or not self._fits(buf, (buf.shape[0], self.B, self.M, 2), torch.float32):
             raise ValueError(f"target trace must be a contiguous float32 [T, {self.B}, {self.M}, 2] tensor on {self.device}")
         _lib.check(self._lib.uavtrack_set_target_trace(self._h, _ptr(buf), C.c_int32(buf.shape[0])), "uavtrack_set_target_trace")
+        self._trace = buf     # every later launch writes through the raw pointer: the tensor must outlive them
 
     def _with_targets(self, T: int, want: bool, o, launch):
         """Run `launch()` with a [T, B, M, 2] target trace attached when asked; returns the trace (or None)."""
@@ -159,11 +162,12 @@ class BatchedUavEnv:
             launch()
             return None
         tp = self._reuse(o, "targets", (T, self.B, self.M, 2), torch.float32)
+        installed = self._trace            # a trace the caller set up earlier comes back afterwards
         self.set_target_trace(tp)
         try:
             launch()
         finally:
-            self.set_target_trace(None)
+            self.set_target_trace(installed)
         return tp
 
     def step_many(self, actions, want_obs: bool = True, want_terms: bool = True, want_ep_sums: bool = True,
@@ -249,12 +253,17 @@ class BatchedUavEnv:
                  tx=self._empty((self.B, self.M), torch.float32), ty=self._empty((self.B, self.M), torch.float32),
                  tz=self._empty((self.B, self.M), torch.float32) if three else None,
                  th=self._empty((self.B, self.M), torch.float32),
-                 step_count=self._empty((self.B,), torch.int32))
+                 step_count=self._empty((self.B,), torch.int32),
+                 episode=self._empty((self.B,), torch.int32))
         _lib.check(self._lib.uavtrack_get_state(self._h, *[_ptr(s[k]) for k in _STATE_KEYS],
                                                 _ptr(s["step_count"]), self._stream()), "uavtrack_get_state")
+        _lib.check(self._lib.uavtrack_get_episodes(self._h, _ptr(s["episode"]), self._stream()), "uavtrack_get_episodes")
         return {k: v for k, v in s.items() if v is not None}
 
-    def set_state(self, ux, uy, uh, ua, tx, ty, th, uz=None, tz=None, step_count=None) -> None:
+    def set_state(self, ux, uy, uh, ua, tx, ty, th, uz=None, tz=None, step_count=None, episode=None) -> None:
+        """Inject a state (parity tests) or restore a get_state() checkpoint: `env.set_state(**ckpt)`.  `episode` [B]
+        (the number of each environment's last reset) keys the next automatic reset; when it is given the host-side
+        episode counter moves past its largest entry, so a later reset() does not replay a used episode number."""
         def f(v, shape, dtype):
             if v is None:
                 return None
@@ -267,8 +276,12 @@ class BatchedUavEnv:
                     tx=f(tx, BM, torch.float32), ty=f(ty, BM, torch.float32), tz=f(tz, BM, torch.float32),
                     th=f(th, BM, torch.float32))
         sc = f(step_count, (self.B,), torch.int32)
+        ep = f(episode, (self.B,), torch.int32)
         _lib.check(self._lib.uavtrack_set_state(self._h, *[_ptr(arrs[k]) for k in _STATE_KEYS], _ptr(sc),
                                                 self._stream()), "uavtrack_set_state")
+        if ep is not None:
+            _lib.check(self._lib.uavtrack_set_episodes(self._h, _ptr(ep), self._stream()), "uavtrack_set_episodes")
+            self._episode = max(self._episode, int(ep.max().item()) + 1)
         # the D2D copies are stream-ordered; keep the sources alive until they have run
         torch.cuda.current_stream(self.device).synchronize()
 
@@ -280,6 +293,17 @@ class BatchedUavEnv:
         blob, hidden = fold_pmi_state_dict(state_dict)
         _lib.check(self._lib.uavtrack_set_pmi_weights(self._h, C.c_void_p(blob.ctypes.data), blob.size, hidden,
                                                       self._stream()), "uavtrack_set_pmi_weights")
+
+    def pmi_inference(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """PMINetwork.inference (PMINet.py:64-72) on a batch of pair inputs x [n, 12] (= la_i * la_j, uav.py:281) with the
+        uploaded weights, on the MAAC-R scorer kernels -> scores [n]."""
+        if x.dim() != 2 or not self._fits(x, (x.shape[0], _lib.OBS_DIM), torch.float32):
+            raise ValueError(f"x must be a contiguous float32 [n, {_lib.OBS_DIM}] tensor on {self.device}")
+        n = int(x.shape[0])
+        s = self._out_arg(out, (n,), torch.float32, "out")
+        _lib.check(self._lib.uavtrack_pmi_inference(self._h, _ptr(x), C.c_int64(n), _ptr(s), self._stream()),
+                   "uavtrack_pmi_inference")
+        return s
 
     def greedy_actions(self, seed: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The reference's C-METHOD baseline policy (uav.py:324-369) for every UAV -> int32 [B, N]."""
@@ -368,6 +392,17 @@ class BatchedUavEnv:
         if tp is not None:
             res["targets"] = tp
         return res
+
+    def set_profiling(self, on: bool) -> None:
+        """HIP event pairs around every kernel launch of the stepping calls (uavtrack_set_profiling); read with profile()."""
+        _lib.check(self._lib.uavtrack_set_profiling(self._h, C.c_int32(1 if on else 0)), "uavtrack_set_profiling")
+
+    def profile(self) -> Dict[str, Dict[str, float]]:
+        """{kernel class: {"ms": total, "launches": n}} since the last call (synchronises the stream)."""
+        ms = (C.c_double * len(_lib.PROF_CLASSES))()
+        cnt = (C.c_int64 * len(_lib.PROF_CLASSES))()
+        _lib.check(self._lib.uavtrack_get_profile(self._h, ms, cnt, self._stream()), "uavtrack_get_profile")
+        return {k: {"ms": float(ms[i]), "launches": int(cnt[i])} for i, k in enumerate(_lib.PROF_CLASSES)}
 
     def pmi_pairs_scored(self) -> int:
         """Neighbour pairs the PMI network has scored so far (synchronises the stream)."""

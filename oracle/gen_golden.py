@@ -18,6 +18,9 @@ Scenarios:
   g5b N50 M25  coop .3  PMI      4 seeds x 25 steps
   g6  reset-only layouts N in {5,10,20,50}
   g7  hand-placed edge cases (walls, wraps, inclusive/strict thresholds, ...)
+  g8  non-default constants (dt .5, v_max 13, h_max pi/5, dp 173.3, dc 411.7, alpha/beta/gamma .5/.3/.2, target v_max 7,
+      na 9, 1500 x 1100 box, reward normalisation by config n_uav / m_targets != the environment's own): N20 M10 MAAC-G
+      and MAAC-R H64, N7 M4 MAAC; 4 seeds x 25 steps each
   greedy  UAV.get_action_by_direction (uav.py:324-369, the C-METHOD baseline): best_angle per UAV on recorded states
 """
 import contextlib
@@ -72,8 +75,10 @@ def make_pmi(hidden=128, seed=42):
     return pmi
 
 
-def run_episode(cfg, pmi, steps, seed=None, init=None, actions=None):
-    """Returns dict of stacked arrays: states [T+1,...], actions [T,N], outputs [T,...]."""
+def run_episode(cfg, pmi, steps, seed=None, init=None, actions=None, step_cfg=None):
+    """Returns dict of stacked arrays: states [T+1,...], actions [T,N], outputs [T,...].
+    step_cfg: the config dict handed to Environment.step when it differs from the one reset() saw (the reward
+    normalisation reads config['environment']['n_uav' / 'm_targets'] per step, environment.py:207-210)."""
     e = cfg["environment"]
     env = Environment(n_uav=e["n_uav"], m_targets=e["m_targets"], x_max=e["x_max"], y_max=e["y_max"], na=e["na"])
     if seed is not None:
@@ -97,7 +102,7 @@ def run_episode(cfg, pmi, steps, seed=None, init=None, actions=None):
         else:
             a = [random.randint(0, e["na"] - 1) for _ in range(e["n_uav"])]
         with contextlib.redirect_stdout(sink):
-            nxt, r, c = env.step(cfg, pmi, a)
+            nxt, r, c = env.step(step_cfg or cfg, pmi, a)
         acts.append(a)
         obs.append(np.array(nxt, dtype=np.float64))
         rew.append(np.array(r["rewards"], dtype=np.float64))
@@ -295,7 +300,33 @@ def gen_h64():
     scenario("g4b_n20m10_pmi_h64", 20, 10, 0.3, pmi, [52, 53, 54, 55], 25)
 
 
+def gen_nondefault():
+    """Every constant of the per-step path away from configs/*.yaml, and the reward normalisation keyed by a config
+    whose n_uav / m_targets differ from the Environment's own (environment.py:207-210 read the dict, not the object)."""
+    pmi = make_pmi(64, 43)
+    arrays, meta = {}, {"cases": []}
+    for tag, n, m, coop, net in (("n20m10_mean", 20, 10, 0.3, None), ("n20m10_pmi_h64", 20, 10, 0.3, pmi), ("n7m4_raw", 7, 4, 0.0, None)):
+        cfg = {
+            "environment": {"n_uav": n, "m_targets": m, "x_max": 1500, "y_max": 1100, "na": 9},
+            "uav": {"dt": 0.5, "v_max": 13, "h_max": 5, "dc": 411.7, "dp": 173.3, "alpha": 0.5, "beta": 0.3, "gamma": 0.2},
+            "target": {"v_max": 7, "h_max": 6},
+            "cooperative": coop,
+        }
+        step_cfg = json.loads(json.dumps(cfg))
+        step_cfg["environment"]["n_uav"] = n + 4          # the clip's N and M (environment.py:208,210)
+        step_cfg["environment"]["m_targets"] = max(1, m - 3)
+        eps = [run_episode(cfg, net, 25, seed=s, step_cfg=step_cfg) for s in (61, 62, 63, 64)]
+        for k, v in stack_eps(eps).items():
+            arrays[f"{tag}__{k}"] = v
+        meta["cases"].append(dict(name=tag, n_uav=n, m_targets=m, cooperative=coop, pmi=net is not None, seeds=[61, 62, 63, 64],
+                                  steps=25, cfg=cfg, norm_n_uav=n + 4, norm_m_targets=max(1, m - 3)))
+    save("g8_nondefault", arrays, meta)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-nondefault":
+        gen_nondefault()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--only-actor":
         gen_actor()
         return
@@ -320,7 +351,8 @@ def main():
     gen_edges(pmi)
     gen_actor()
     gen_greedy()
-    gen_h64()       # (last: nothing above depends on what it does to the global RNGs)
+    gen_h64()       # (nothing above depends on what it does to the global RNGs)
+    gen_nondefault()
 
 
 if __name__ == "__main__":

@@ -343,3 +343,56 @@ def test_pmi_net_is_state_dict_compatible_and_folds(pmi_state_dict):
                         np.maximum(xn[:, 9:12] @ wb + bb, 0)], axis=1)
     got = np.maximum(a @ w1 + b1, 0) @ w2 + b2
     np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
+
+
+def test_x6_split_error_model_on_adversarial_sums():
+    """The arithmetic of pmi_score_x6_kernel (csrc/pmi_kernel.hip) emulated in numpy (tools/x6_accuracy.py, now part of
+    the suite): fp32 = three bf16 parts by truncation; a product is the six bf16 products of total order <= 2, exact, with
+    fp32 accumulation per 16-wide k-step.  On well-scaled data AND on the adversarial layer of conftest (magnitudes over
+    2^-20 .. 2^4, every 384-term sum a ~1000-fold cancellation) the six-term scheme is as accurate as an fp32 fmaf chain
+    (what the fp32 MFMA and the reference's fp32 torch deliver) and within 1e-5 of sum |terms|; three terms are not
+    enough.  The kernel itself is checked against fp64 on the GPU (tests/test_hip_round3.py)."""
+    from conftest import adversarial_pmi_state_dict
+
+    def trunc(a):
+        return (a.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+
+    def split3(a):
+        h = trunc(a)
+        r1 = (a - h).astype(np.float32)
+        m = trunc(r1)
+        return h, m, trunc((r1 - m).astype(np.float32))
+
+    def mm(a, b, acc=None):
+        acc = np.zeros((a.shape[0], b.shape[1]), np.float32) if acc is None else acc
+        for k in range(0, a.shape[1], 16):           # one MFMA: exact products, one fp32 rounding of the k-step's sum
+            acc = (acc.astype(np.float64) + a[:, k:k + 16].astype(np.float64) @ b[k:k + 16].astype(np.float64)).astype(np.float32)
+        return acc
+
+    rng = np.random.RandomState(0)
+    K, N, M = 384, 128, 256
+    cases = {"well_scaled": (np.maximum(rng.randn(M, K).astype(np.float32) * 3, 0), (rng.randn(K, N) * 0.1).astype(np.float32))}
+    sd = adversarial_pmi_state_dict(128, seed=1)
+    h = np.repeat(np.abs(rng.randn(M, K // 2)).astype(np.float32) * 2, 2, axis=1)      # twin activations
+    cases["adversarial"] = (h, np.ascontiguousarray(sd["fc1.weight"].T))
+    for name, (x, w) in cases.items():
+        ref = x.astype(np.float64) @ w.astype(np.float64)
+        mag = np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64)
+        xh, xm, xl = split3(x)
+        wh, wm, wl = split3(w)
+        # the kernel's order: small terms first, ONE accumulation chain (pmi_score_x6_kernel, t = 0..5 per k-step)
+        six = np.zeros((M, N), np.float32)
+        three = np.zeros((M, N), np.float32)
+        for k in range(0, K, 16):
+            sl = slice(k, k + 16)
+            for a, b in ((xh, wl), (xl, wh), (xm, wm), (xm, wh), (xh, wm), (xh, wh)):
+                six = mm(a[:, sl], b[sl], six)
+            for a, b in ((xm, wh), (xh, wm), (xh, wh)):
+                three = mm(a[:, sl], b[sl], three)
+        chain = np.zeros((M, N), np.float32)
+        for k in range(K):
+            chain = (chain.astype(np.float64) + x[:, k:k + 1].astype(np.float64) * w[k:k + 1].astype(np.float64)).astype(np.float32)
+        e6, e3, ec = np.abs(six - ref), np.abs(three - ref), np.abs(chain - ref)
+        assert (e6 <= 1e-5 * np.maximum(mag, 1.0)).all(), (name, e6.max(), mag.max())
+        assert e6.max() <= 2.0 * ec.max() + 1e-6 * mag.max(), (name, e6.max(), ec.max())
+        assert e3.max() > 8.0 * e6.max(), (name, e3.max(), e6.max())       # why six products, not three

@@ -16,10 +16,23 @@ def ang_diff(a, b):
     return np.abs(d)
 
 
+def oracle_cfg_of(case, n_envs=1):
+    """OracleConfig of a golden case; cases recorded with non-default constants carry their reference config dict
+    (`cfg`) and the n_uav / m_targets the per-step config normalised the rewards with."""
+    kw = dict(n_envs=n_envs, n_uav=case["n_uav"], m_targets=case["m_targets"], cooperative=case["cooperative"])
+    if "norm_n_uav" in case:
+        c = case["cfg"]
+        e, u, t = c["environment"], c["uav"], c["target"]
+        kw.update(x_max=float(e["x_max"]), y_max=float(e["y_max"]), na=int(e["na"]), dt=float(u["dt"]), u_v_max=float(u["v_max"]),
+                  u_h_max=np.pi / float(u["h_max"]), dc=float(u["dc"]), dp=float(u["dp"]), alpha=float(u["alpha"]),
+                  beta=float(u["beta"]), gamma=float(u["gamma"]), t_v_max=float(t["v_max"]),
+                  norm_n_uav=case["norm_n_uav"], norm_m_targets=case["norm_m_targets"])
+    return kw
+
+
 def check_episode(z, pre, e, meta_case, pmi_sd, steps):
     """Teacher-forced: inject the reference state before every step, run one oracle step."""
-    n, m = meta_case["n_uav"], meta_case["m_targets"]
-    cfg = OracleConfig(n_envs=1, n_uav=n, m_targets=m, cooperative=meta_case["cooperative"])
+    cfg = OracleConfig(**oracle_cfg_of(meta_case))
     env = OracleEnv(cfg)
     if meta_case["pmi"]:
         env.pmi = OraclePmi.from_state_dict(pmi_sd)
@@ -60,6 +73,17 @@ def test_teacher_forced_pmi_default_width(pmi_state_dict_h64):
     assert int(z["overstep_prints"].sum()) == 0
     for e in range(len(meta["seeds"])):
         check_episode(z, "", e, meta, pmi_state_dict_h64, meta["steps"])
+
+
+def test_teacher_forced_nondefault_constants(pmi_state_dict_h64):
+    """g8: dt, speeds, turn limit, ranges, reward weights, action count and box all away from configs/*.yaml, and the
+    clip's N / M taken from a config that differs from the Environment's own sizes (environment.py:207-210)."""
+    z, meta = load_golden("g8_nondefault")
+    for case in meta["cases"]:
+        pre = case["name"] + "__"
+        assert int(z[pre + "overstep_prints"].sum()) == 0
+        for e in range(len(case["seeds"])):
+            check_episode(z, pre, e, case, pmi_state_dict_h64, case["steps"])
 
 
 def test_free_running_rollout():
