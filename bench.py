@@ -420,7 +420,12 @@ def pmi_roofline(args, roof, units_per_launch):
     H = args.pmi_hidden
     flop_pair = 2.0 * (12 * H + 3 * H * H + H)               # 101 632 at H = 128
     hp = (H + 31) // 32 * 32
-    x6 = 64 <= hp <= 128 and os.environ.get("UAVTRACK_PMI_FP32", "0") in ("", "0")
+    scheme_env = os.environ.get("UAVTRACK_PMI_SCHEME", "")
+    fp32_forced = os.environ.get("UAVTRACK_PMI_FP32", "0") not in ("", "0") or scheme_env == "fp32"
+    split = 64 <= hp <= 128 and not fp32_forced
+    # f16 x 3 (pmi_score_h3_kernel) unless forced otherwise; the library itself falls back to bf16 x 6 for networks whose
+    # operands could leave f16's range (none of the synthetic / reference-initialised ones do)
+    scheme = "fp32" if not split else ("x6" if scheme_env == "x6" else "h3")
     call_s = sum(roof["ms"]) * 1e-3
     sc = roof["kernels"].get("scorer", {"ms": 0.0, "launches": 0})
     scorer_s = sc["ms"] * 1e-3 if sc["launches"] else call_s
@@ -432,24 +437,28 @@ def pmi_roofline(args, roof, units_per_launch):
         "pairs_per_agent_step": pairs / (units_per_launch * roof["launches"]),
         "timing": "library-side HIP events on the launch stream around every scorer launch of the fixed leg "
                   "(uavtrack_set_profiling); whole_call_* divide by the events around the uavtrack_step_many calls instead "
-                  "(rollout + scorer + mix + episode sums of every chunk)",
+                  "(rollout + scorer + mix + episode return of every chunk)",
         "scorer_ms_per_launch": scorer_s * 1e3 / roof["launches"],
         "fp32_equivalent_tflops": tf_scorer, "fp32_equivalent_over_fp32_mfma_peak": tf_scorer / FP32_MFMA_PEAK_TFLOPS,
         "whole_call_fp32_equivalent_tflops": tf_call,
         **leg_summary(roof),
     }
-    if x6:
-        # pmi_score_x6_kernel: the 3H x H layer as SIX bf16 MFMAs per fp32 product (three-way bf16 split, fp32
-        # accuracy).  The roof that bounds it is the bf16 matrix rate; `achieved` counts the bf16 flops the
-        # matrix cores really execute (6 x 2 x 3H x H per pair), not the fp32-equivalent work.
-        executed = pairs * 6.0 * 2.0 * 3 * hp * hp
+    if split:
+        # The 3H x H layer at fp32 accuracy on the 16-bit matrix cores: an fp32 operand is split into f16 (hi, lo * 2^11:
+        # THREE MFMAs per fp32 product, pmi_score_h3_kernel) or bf16 (three parts: SIX, pmi_score_x6_kernel) terms.  The
+        # roof that bounds it is the 16-bit matrix rate (f16 and bf16 MFMAs take the same cycles); `achieved` counts the
+        # flops the matrix cores really execute, not the fp32-equivalent work.
+        nprod = 3.0 if scheme == "h3" else 6.0
+        executed = pairs * nprod * 2.0 * 3 * hp * hp
         return {
-            "bound": "mfma", "kernel": f"pmi_score_x6_kernel<{hp}>", "achieved": executed / scorer_s / 1e12,
+            "bound": "mfma", "kernel": f"pmi_score_{scheme}_kernel<{hp}>", "achieved": executed / scorer_s / 1e12,
             "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": executed / scorer_s / 1e12 / BF16_MFMA_PEAK_TFLOPS,
-            "whole_call_frac": executed / call_s / 1e12 / BF16_MFMA_PEAK_TFLOPS, **common,
-            "peak_note": "bf16 MFMA dense peak (~2.5 PFLOP/s, MI355X_MICROARCH.md); executed flops = 6 bf16 MFMAs per "
-                         "fp32 product; fp32_equivalent_* restate the same time as plain fp32 work against the 157.3 "
-                         "TFLOP/s fp32-MFMA peak the round-1 scorer was bounded by",
+            "whole_call_frac": executed / call_s / 1e12 / BF16_MFMA_PEAK_TFLOPS, "mfma_products_per_fp32_product": nprod, **common,
+            "peak_note": "f16 / bf16 MFMA dense peak (~2.5 PFLOP/s, MI355X_MICROARCH.md); executed flops = 3 (f16 split) or 6 (bf16 "
+                         "split) MFMAs per fp32 product; fp32_equivalent_* restate the same time as plain fp32 work against the "
+                         "157.3 TFLOP/s fp32-MFMA peak.  With three products per fp32 product the kernel is bound by the VALU work "
+                         "beside the MFMAs (branch layers, ReLU, operand split), not by the matrix pipe: a lower fraction of this "
+                         "roof than the six-product kernel reached, in two thirds of its time",
         }
     return {
         "bound": "mfma", "kernel": f"pmi_score_kernel<{hp}>", "achieved": tf_scorer, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

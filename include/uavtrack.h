@@ -252,7 +252,7 @@ int uavtrack_pmi_pairs_scored(uavtrack_env *env, uint64_t *out, void *stream);
 enum { UAVTRACK_PROF_ROLLOUT = 0,   /* rollout_kernel: the fused environment step(s) */
        UAVTRACK_PROF_SCORER  = 1,   /* MAAC-R: pmi_score_x6_kernel / pmi_score_kernel */
        UAVTRACK_PROF_MIX     = 2,   /* MAAC-R: pmi_mix_kernel (softmax mix + final clip) */
-       UAVTRACK_PROF_EPSUMS  = 3,   /* MAAC-R: ep_sums_kernel */
+       UAVTRACK_PROF_EPSUMS  = 3,   /* MAAC-R: ep_reward_kernel (episode return from the per-step means) */
        UAVTRACK_PROF_CLASSES = 4 };
 int uavtrack_set_profiling(uavtrack_env *env, int32_t on);
 int uavtrack_get_profile(uavtrack_env *env, double *ms, int64_t *launches, void *stream);

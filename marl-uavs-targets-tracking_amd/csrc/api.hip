@@ -95,7 +95,7 @@ void free_state(uavtrack_env *env)
 {
     drop_profile(env);
     void *ptrs[] = {env->slab, env->pmi.blob, env->actor_w, env->pairs, env->pair_count, env->pair_total, env->scores, env->nbrec,
-                    env->obs_tmp, env->terms_tmp, env->covered_tmp, env->inf_obs, env->inf_pairs};
+                    env->obs_tmp, env->rsum, env->inf_obs, env->inf_pairs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -135,8 +135,7 @@ int ensure_pmi_scratch(uavtrack_env *env, int32_t steps, hipStream_t st)
     const size_t BN = (size_t)c.n_envs * c.n_uav;
     const size_t pairs_step = BN * (c.n_uav - 1) / 2 + 1;
     const size_t rec_bytes = (size_t)nbrec_words(c.n_uav) * 4;
-    const size_t per_step = pairs_step * (sizeof(uint2) + 4) + BN * rec_bytes + BN * UAVTRACK_OBS_DIM * 4 + 3 * BN * 4 +
-                            (size_t)c.n_envs * 4;
+    const size_t per_step = pairs_step * (sizeof(uint2) + 4) + BN * rec_bytes + BN * UAVTRACK_OBS_DIM * 4 + (size_t)c.n_envs * 4;
     size_t budget = (size_t)2048 << 20;
     if (const char *s = getenv("UAVTRACK_PMI_SCRATCH_MB")) budget = (size_t)atoll(s) << 20;
     int64_t cap = (int64_t)(budget / per_step);
@@ -146,19 +145,17 @@ int ensure_pmi_scratch(uavtrack_env *env, int32_t steps, hipStream_t st)
     if (cap > steps) cap = steps;
     if (cap <= env->pmi_steps_cap) return 0;
     HIP_TRY(hipStreamSynchronize(st));
-    void *old[] = {env->pairs, env->scores, env->nbrec, env->obs_tmp, env->terms_tmp, env->covered_tmp};
+    void *old[] = {env->pairs, env->scores, env->nbrec, env->obs_tmp, env->rsum};
     for (void *q : old)
         if (q) (void)hipFree(q);
-    env->pairs = nullptr; env->scores = nullptr; env->nbrec = nullptr; env->obs_tmp = nullptr; env->terms_tmp = nullptr;
-    env->covered_tmp = nullptr;
+    env->pairs = nullptr; env->scores = nullptr; env->nbrec = nullptr; env->obs_tmp = nullptr; env->rsum = nullptr;
     env->pmi_steps_cap = 0;
     const size_t S = (size_t)cap;
     HIP_TRY(dmalloc(&env->pairs, S * pairs_step));
     HIP_TRY(dmalloc(&env->scores, S * pairs_step));
     HIP_TRY(dmalloc(&env->nbrec, S * BN * nbrec_words(c.n_uav)));
     HIP_TRY(dmalloc(&env->obs_tmp, S * BN * UAVTRACK_OBS_DIM));
-    HIP_TRY(dmalloc(&env->terms_tmp, S * 3 * BN));
-    HIP_TRY(dmalloc(&env->covered_tmp, S * (size_t)c.n_envs));
+    HIP_TRY(dmalloc(&env->rsum, S * (size_t)c.n_envs));
     if (!env->pair_count) {
         HIP_TRY(dmalloc(&env->pair_count, 1));
         HIP_TRY(hipMemsetAsync(env->pair_count, 0, sizeof(unsigned), st));
@@ -406,12 +403,14 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
     const int hp = pmi_padded_hidden(hidden);
     const size_t HP = (size_t)hp, n_dev = 12 * HP + 3 * HP + 3 * HP * HP + HP + HP + 1;
     const size_t x6_off = (n_dev + 3) & ~(size_t)3, x6_len = pmi_x6_floats(hp);     // the bf16 planes, 16-B aligned
+    const size_t h3_off = x6_off + x6_len, h3_len = pmi_h3_floats(hp);               // the f16 planes behind them
     if (env->pmi.n_floats != n_dev) {
         HIP_TRY(hipStreamSynchronize(st));
         if (env->pmi.blob) (void)hipFree(env->pmi.blob);
         env->pmi = PmiWeights();
-        HIP_TRY(dmalloc(&env->pmi.blob, x6_off + x6_len));
+        HIP_TRY(dmalloc(&env->pmi.blob, h3_off + h3_len));
     }
+    bool h3_ok = h3_len != 0;
     {   // fc1 goes up in the scorer's register order; the copy has completed before `packed` dies
         std::vector<float> padded(n_dev, 0.0f), packed(n_dev);
         const float *src = folded;
@@ -438,9 +437,40 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
             pack_pmi_x6(padded.data(), planes.data(), hp);
             HIP_TRY(hipMemcpyAsync(env->pmi.blob + x6_off, planes.data(), x6_len * 4, hipMemcpyHostToDevice, st));
         }
+        // The f16 x 3 scorer (pmi_score_h3_kernel) needs every MFMA operand inside f16's range (65504): the fc1 weights
+        // are known here, the branch activations are bounded from the ranges of the observation products x = la_i * la_j
+        // (uav.py:156-197: normalised offsets and action differences within [-1, 1], heading terms within +-(1 + v_t/v_u),
+        // positions / dc taken up to three field lengths outside the box).  A network beyond half that range keeps the
+        // bf16 x 6 kernel (bf16 has fp32's exponent).
+        std::vector<uint16_t> planes3(h3_len * 2);
+        if (h3_ok) {
+            const uavtrack_config &c = env->cfg;
+            const double vr = 1.0 + c.t_v_max / c.u_v_max, pos = 4.0 * std::fmax(c.x_max, c.y_max) / c.dc;
+            const double xb[12] = {1, 1, 4, 4, 1, 1, 1, vr * vr, vr * vr, pos * pos, pos * pos, 1};
+            const float *pw = padded.data();
+            double act_max = 0.0, w_max = 0.0;
+            const int fan[3] = {5, 4, 3};
+            int k0 = 0;
+            for (int br = 0; br < 3; ++br) {              // W[fan][HP] then b[HP]
+                for (size_t u = 0; u < HP; ++u) {
+                    double a = std::fabs(pw[(size_t)fan[br] * HP + u]);
+                    for (int k = 0; k < fan[br]; ++k) a += std::fabs(pw[(size_t)k * HP + u]) * xb[k0 + k];
+                    act_max = std::fmax(act_max, a);
+                }
+                pw += (size_t)(fan[br] + 1) * HP;
+                k0 += fan[br];
+            }
+            for (size_t k = 0; k < 3 * HP * HP; ++k) w_max = std::fmax(w_max, std::fabs(pw[k]));
+            h3_ok = std::isfinite(act_max) && act_max < 32000.0 && w_max < 32000.0;
+        }
+        if (h3_ok) {
+            pack_pmi_h3(padded.data(), planes3.data(), hp);
+            HIP_TRY(hipMemcpyAsync(env->pmi.blob + h3_off, planes3.data(), h3_len * 4, hipMemcpyHostToDevice, st));
+        }
         HIP_TRY(hipStreamSynchronize(st));
     }
     env->pmi.x6 = x6_len ? env->pmi.blob + x6_off : nullptr;
+    env->pmi.h3 = h3_ok ? env->pmi.blob + h3_off : nullptr;
     env->pmi.hidden = hp;
     env->pmi.n_floats = n_dev;
     if (ensure_pmi_scratch(env, 1, st)) return 1;
@@ -525,7 +555,9 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
     if (ensure_pmi_scratch(env, T, st)) return 1;
     const uavtrack_config &c = env->cfg;
     const size_t BN = (size_t)c.n_envs * c.n_uav;
-    p.ep_sums = nullptr;
+    // episode sums: the three terms and the coverage are summed by the rollout kernel (registers, as in the other modes),
+    // the return by the mix stage (per-step means) and a one-lane-per-environment reduction over the chunk's steps
+    p.ep_sums = ep_sums;
     p.nbrec = env->nbrec;
     p.pairs = env->pairs;
     p.pair_count = env->pair_count;      // zero: set at allocation, re-zeroed by the mix kernel
@@ -533,11 +565,11 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
     for (int32_t t0 = 0; t0 < T; t0 += env->pmi_steps_cap) {
         const int32_t n = (T - t0 < env->pmi_steps_cap) ? T - t0 : env->pmi_steps_cap;
         float *obs_t = obs ? obs + (size_t)t0 * BN * UAVTRACK_OBS_DIM : env->obs_tmp;
-        float *terms_t = terms ? terms + (size_t)t0 * 3 * BN : (ep_sums ? env->terms_tmp : nullptr);
+        float *terms_t = terms ? terms + (size_t)t0 * 3 * BN : nullptr;
         float *reward_t = reward + (size_t)t0 * BN;
-        // (the episode sums need the coverage counts even when the caller does not ask for them)
-        int32_t *covered_t = covered ? covered + (size_t)t0 * c.n_envs : (ep_sums ? env->covered_tmp : nullptr);
+        int32_t *covered_t = covered ? covered + (size_t)t0 * c.n_envs : nullptr;
         p.T = n;
+        p.ep_accumulate = add ? 1 : 0;
         p.actions = actions ? actions + (size_t)t0 * BN : nullptr;
         p.actions_out = pol.actions_out ? pol.actions_out + (size_t)t0 * BN : nullptr;
         p.obs = obs_t; p.reward = reward_t; p.terms = terms_t;
@@ -549,9 +581,9 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
         // once, at launch start, before it writes anything: the scratch buffer may be reused in place)
         p.obs_in = obs_t + (size_t)(n - 1) * BN * UAVTRACK_OBS_DIM;
         HIP_TRY(timed_launch(env, UAVTRACK_PROF_SCORER, st, [&] { return launch_pmi_score(env, obs_t, st); }));
-        HIP_TRY(timed_launch(env, UAVTRACK_PROF_MIX, st, [&] { return launch_pmi_finalize(env, n, reward_t, st); }));
+        HIP_TRY(timed_launch(env, UAVTRACK_PROF_MIX, st, [&] { return launch_pmi_finalize(env, n, reward_t, ep_sums ? env->rsum : nullptr, st); }));
         if (ep_sums) {
-            HIP_TRY(timed_launch(env, UAVTRACK_PROF_EPSUMS, st, [&] { return launch_ep_sums(env, n, reward_t, terms_t, covered_t, ep_sums, add, st); }));
+            HIP_TRY(timed_launch(env, UAVTRACK_PROF_EPSUMS, st, [&] { return launch_ep_reward(env, n, env->rsum, ep_sums, add, st); }));
             add = true;
         }
     }

@@ -109,6 +109,8 @@ __host__ __device__ inline int nbrec_words(int N) { return nbrec_mask_words(N) +
 struct PmiWeights {
     float *blob = nullptr;   // device, folded layout of uavtrack_set_pmi_weights; behind it the bf16 planes of fc1
     const void *x6 = nullptr; // -> into blob: fc1 as three bf16 planes in MFMA operand order (pack_pmi_x6), or null
+    const void *h3 = nullptr; // -> into blob: fc1 as two f16 planes (hi, lo * 2^11) in MFMA operand order (pack_pmi_h3), or null
+                              //    (also null when the network's weights / activation bounds do not fit f16's range)
     int32_t hidden = 0;
     size_t n_floats = 0;
 };
@@ -142,11 +144,11 @@ struct uavtrack_env {
     uint2 *pairs = nullptr;
     unsigned *pair_count = nullptr;
     unsigned long long *pair_total = nullptr;
-    float *scores = nullptr, *obs_tmp = nullptr, *terms_tmp = nullptr;   // scores: one per emitted pair
+    float *scores = nullptr, *obs_tmp = nullptr;   // scores: one per emitted pair
     uint32_t *nbrec = nullptr;
     float2 *tpos = nullptr;           // caller's target-trace buffer (not owned), capacity in steps
     int32_t tpos_steps = 0;
-    int32_t *covered_tmp = nullptr;   // [steps][B] coverage counts for ep_sums when the caller passes covered = NULL
+    float *rsum = nullptr;            // [steps][B] per-step mean of the final reward (mix kernel -> episode return)
     // uavtrack_set_profiling: a HIP event pair on the launch stream around every kernel launch of the stepping entry points,
     // by kernel class (UAVTRACK_PROF_*); read and cleared by uavtrack_get_profile
     struct ProfRec { int cls; hipEvent_t a, b; };
@@ -174,13 +176,14 @@ constexpr int kPmiX6MaxHidden = 128;                // widest layer whose three 
 constexpr int kPmiX6MinHidden = 64;                 // (narrower layers have fewer k-steps than the producer has pairs to hide)
 inline size_t pmi_x6_floats(int hp) { return hp >= kPmiX6MinHidden && hp <= kPmiX6MaxHidden ? (size_t)3 * hp * hp * 3 / 2 : 0; }   // 3 planes x 2 B
 void pack_pmi_x6(const float *abi_blob, uint16_t *planes, int hidden);
+inline size_t pmi_h3_floats(int hp) { return hp >= kPmiX6MinHidden && hp <= kPmiX6MaxHidden ? (size_t)3 * hp * hp : 0; }   // 2 planes x 2 B
+void pack_pmi_h3(const float *abi_blob, uint16_t *planes, int hidden);
 // (pairs / scores / n_uav default to the handle's MAAC-R scratch and swarm size; uavtrack_pmi_inference passes its own)
 hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream_t stream, const uint2 *pairs = nullptr,
                             float *scores = nullptr, int n_uav = 0);
 hipError_t launch_pmi_inference_prep(const float *x, float *obs2, uint2 *pairs, unsigned n, hipStream_t stream);
-hipError_t launch_pmi_finalize(const uavtrack_env *env, int steps, float *reward, hipStream_t stream);
-hipError_t launch_ep_sums(const uavtrack_env *env, int steps, const float *reward, const float *terms,
-                          const int32_t *covered, float *ep_sums, bool add, hipStream_t stream);
+hipError_t launch_pmi_finalize(const uavtrack_env *env, int steps, float *reward, float *rsum, hipStream_t stream);
+hipError_t launch_ep_reward(const uavtrack_env *env, int steps, const float *rsum, float *ep_sums, bool add, hipStream_t stream);
 
 // policy_kernel.hip
 hipError_t launch_greedy(const uavtrack_env *env, uint64_t seed, int32_t *actions, hipStream_t stream);

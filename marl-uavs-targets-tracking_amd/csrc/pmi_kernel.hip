@@ -59,6 +59,7 @@ __device__ __forceinline__ float half_wave_sum(float v)
 struct PmiParams {
     const float *blob;       // folded weights, layout of uavtrack_set_pmi_weights
     const void *x6;          // fc1 as three bf16 planes in MFMA B-operand order (pack_pmi_x6)
+    const void *h3;          // fc1 as two f16 planes (hi, lo * 2^11) in MFMA B-operand order (pack_pmi_h3), or null
     const float *obs;        // [S][B][N][12] local states of the chunk's steps
     const uint2 *pairs;      // {flat [step][b][i] index of i within the chunk, j}
     const unsigned *pair_count;
@@ -588,10 +589,295 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// pmi_score_h3_kernel<H>: the same weight-stationary scorer on the F16 matrix cores -- THREE MFMAs per fp32 product
+// instead of six, at the same accuracy.  f16 keeps 11 significant bits, so an fp32 value is a two-term sum to 2^-22:
+//     x = xh + xl * 2^-11,   xh = f16(x),  xl = f16((x - xh) * 2^11)       (the remainder is exact in fp32; scaled so
+// that it stays a NORMAL f16 number whatever the magnitude of x -- an unscaled remainder of a weight of 0.05 would sit
+// in the subnormal range and keep four bits), and
+//     x * w = xh*wh + 2^-11 (xh*wl + xl*wh) + O(2^-22 |x w|)
+// -- v_mfma_f32_32x32x16_f16 (the bf16 form's rate): products exact, fp32 accumulate, the two orders of magnitude in TWO
+// accumulators that are combined once per tile (acc_hi + 2^-11 acc_lo).  Emulated in numpy against fp64 (tests/
+// test_host_cpu.py) its error is that of the bf16 x 6 scheme and of an fp32 fmaf chain -- the fp32 accumulation, not the
+// split, sets it -- and the GPU tests hold it to the same bounds.  f16's range is the one thing bf16 did not have to
+// think about: operands beyond 65504 would saturate, so uavtrack_set_pmi_weights bounds the weights and the branch
+// activations (from the observation ranges) on the host and keeps the bf16 x 6 kernel for networks that could get there.
+// Everything else -- stationary planes in the accumulation-register file, producer atoms dealt behind the MFMAs,
+// LDS-only tile barrier, pipelined pair gather, epilogue under the next tile -- is pmi_score_x6_kernel's; with half
+// the MFMAs per tile the kernel is now bound by the producer's VALU work, not by the matrix pipe.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f16x8 as_f16x8(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
+constexpr float kH3LoScale = 2048.0f, kH3LoInv = 1.0f / 2048.0f;
+// two floats -> one 32-bit word of two f16 (.x in the low half), round toward zero: ONE instruction for the pair; the
+// remainder below is taken against the value that was really stored, so the rounding mode does not enter the result
+__device__ __forceinline__ unsigned pk_f16(f2 v) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v.x, v.y)); }
+__device__ __forceinline__ f2 unpk_f16(unsigned w)
+{
+    const f16x2 h = __builtin_bit_cast(f16x2, w);
+    return f2{(float)h.x, (float)h.y};
+}
+__device__ __forceinline__ f2 scale2(f2 v, float k) { return f2{v.x * k, v.y * k}; }
+
+template <int H>
+__global__ void __launch_bounds__(H * 2, 1) pmi_score_h3_kernel(const PmiParams q)
+{
+    constexpr int K = 3 * H;             // fc1 input width
+    constexpr int KS = K / 16;           // MFMA k-steps (32x32x16)
+    constexpr int PITCH = K * 2 + 16;    // bytes per activation row of one plane
+    constexpr int PLANE = 32 * PITCH;    // bytes per plane of a tile
+    constexpr int NP = 2;                // planes: hi, lo * 2^11
+    constexpr int NW = H / 32;           // wavefronts = column blocks
+    constexpr int NT = NW * 64;          // threads = 2 H
+    constexpr int OP = H / 2;            // adjacent-output pairs per branch
+    constexpr int PG = NT / OP;          // pair groups (4)
+    constexpr int PPT = 32 / PG;         // pairs per thread in the branch layers (8)
+    static_assert(KS >= PPT, "every produced pair needs at least one k-step to hide behind");
+
+    __shared__ float4 lds4[(2 * NP * PLANE + (2 * 32 * 12 + 2 * NW * 64 + NW * 96) * 4) / 16 + 2];
+    static_assert(H != 64 || 2 * sizeof(lds4) <= 160 * 1024, "two H = 64 workgroups no longer share a CU");
+    unsigned char *aplanes = reinterpret_cast<unsigned char *>(lds4);               // [2 tiles][2 planes][32 pairs][PITCH]
+    float *xs = reinterpret_cast<float *>(aplanes + 2 * NP * PLANE);               // [2 tiles][32 pairs][12]
+    float *part = xs + 2 * 32 * 12;                                                // [2 tiles][NW][2 column halves][32]
+    float *sink = part + 2 * NW * 64;                                              // [NW][96] where non-writer lanes' stores go
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int col = w * 32 + (lane & 31);
+    const int kh = lane >> 5;
+
+    // ---- stationary operands: the two f16 planes of fc1's slice, in MFMA B-operand order (pack_pmi_h3), both parked
+    //      in the accumulation-register file for the lifetime of the workgroup (192 of its 256 registers at H = 128)
+    const float *W1 = q.blob + 15 * H;
+    const float *b1 = W1 + (size_t)K * H;
+    const float *w2 = b1 + H;
+    const float b2 = w2[H];
+    u32x4 Bh[KS], Bl[KS];
+    {
+        const u32x4 *bp = reinterpret_cast<const u32x4 *>(q.h3) + (size_t)w * NP * KS * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            Bh[s] = bp[(0 * KS + s) * 64];
+            Bl[s] = bp[(1 * KS + s) * 64];
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { asm volatile("" : "+a"(Bh[s])); asm volatile("" : "+a"(Bl[s])); }
+    }
+    const float bias1 = b1[col], wout = w2[col];
+    f32x16 biasv;                            // fc1's bias as the first hi-order MFMA's srcC
+#pragma unroll
+    for (int r = 0; r < 16; ++r) biasv[r] = bias1;
+
+    // Branch layers (PMINet.py:50-55): thread (o2, pg) owns outputs 2 o2 and 2 o2 + 1 of each of the three branches
+    // for PPT of the tile's 32 pairs; its 30 folded weights and 6 biases stay in registers.
+    const int o2 = tid % OP, pg = tid / OP;
+    f2 wc[5], wo[4], wb[3], bc, bo, bb;
+    {
+        const int o = 2 * o2;
+#pragma unroll
+        for (int v = 0; v < 5; ++v) wc[v] = f2{q.blob[v * H + o], q.blob[v * H + o + 1]};
+        bc = f2{q.blob[5 * H + o], q.blob[5 * H + o + 1]};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) wo[v] = f2{q.blob[6 * H + v * H + o], q.blob[6 * H + v * H + o + 1]};
+        bo = f2{q.blob[10 * H + o], q.blob[10 * H + o + 1]};
+#pragma unroll
+        for (int v = 0; v < 3; ++v) wb[v] = f2{q.blob[11 * H + v * H + o], q.blob[11 * H + v * H + o + 1]};
+        bb = f2{q.blob[14 * H + o], q.blob[14 * H + o + 1]};
+    }
+    const int arow0 = (pg * PPT) * PITCH + 4 * o2;
+    const int afrag0 = (lane & 31) * PITCH + kh * 16;
+
+    const unsigned npairs = *q.pair_count;
+    const unsigned ntiles = (npairs + 31) >> 5;
+    const unsigned G = gridDim.x;
+    if (blockIdx.x == 0 && tid == 0) *q.pair_total += npairs;      // accounting only (one writer)
+
+    // input pipeline of pmi_score_x6_kernel: pair record three tiles ahead, its observations two
+    auto load_rec = [&](unsigned tile, uint2 &pr, bool &ok) {
+        const unsigned pi = tile * 32 + tid;
+        ok = tid < 32 && tile < ntiles && pi < npairs;
+        pr = make_uint2(0, 0);
+        if (ok) pr = q.pairs[pi];
+    };
+    auto load_obs = [&](uint2 pr, bool ok, float4 (&a)[3], float4 (&b)[3]) {
+        a[0] = a[1] = a[2] = b[0] = b[1] = b[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+            const unsigned gi = pr.x, gj = (pr.x / q.N) * q.N + pr.y;
+            const float4 *oi = reinterpret_cast<const float4 *>(q.obs + (size_t)gi * 12);
+            const float4 *oj = reinterpret_cast<const float4 *>(q.obs + (size_t)gj * 12);
+#pragma unroll
+            for (int v = 0; v < 3; ++v) { a[v] = oi[v]; b[v] = oj[v]; }
+        }
+    };
+    auto stash = [&](int buf, const float4 (&a)[3], const float4 (&b)[3]) {
+        if (tid < 32) {
+            float4 *dst = reinterpret_cast<float4 *>(xs + buf * 32 * 12 + tid * 12);
+#pragma unroll
+            for (int v = 0; v < 3; ++v) dst[v] = make_float4(a[v].x * b[v].x, a[v].y * b[v].y, a[v].z * b[v].z, a[v].w * b[v].w);
+        }
+    };
+    // One pair of the branch layers as kMicro atoms of one or two instructions: 12 FMA pairs, 3 ReLU pairs, and per
+    // branch the two-term f16 split -- pack (one v_cvt_pkrtz for the pair), store, convert back, exact remainder, scale,
+    // pack, store -- the three branches taking turns so that no atom waits for the one just before it.
+    constexpr int kMicro = 36, kLoadAtom = 20;
+    struct Prod { float4 x[3]; f2 v[3], hi[3]; unsigned pk[3]; };
+    auto load_x = [&](int xbuf, int pp, Prod &P) {
+        const float4 *xp = reinterpret_cast<const float4 *>(xs + xbuf * 32 * 12 + (pg * PPT + pp) * 12);
+        P.x[0] = xp[0]; P.x[1] = xp[1]; P.x[2] = xp[2];
+    };
+    auto micro = [&](Prod &P, auto opc, int xbuf, int abuf, int pp) {
+        constexpr int op = decltype(opc)::value;
+        unsigned char *dst = aplanes + abuf * NP * PLANE + arow0 + pp * PITCH;
+        if constexpr (op < 12) {
+            constexpr int br = op < 9 ? op % 3 : op < 11 ? op - 9 : 0;          // c o b  c o b  c o b  c o  c
+            constexpr int kk = op < 9 ? op / 3 : op < 11 ? 3 : 4;               // position inside the branch's chain
+            constexpr int i = br == 0 ? kk : br == 1 ? 5 + kk : 9 + kk;
+            const float4 &f = P.x[i / 4];
+            const float xi = i % 4 == 0 ? f.x : i % 4 == 1 ? f.y : i % 4 == 2 ? f.z : f.w;
+            const f2 wgt = br == 0 ? wc[min_c(kk, 4)] : br == 1 ? wo[min_c(kk, 3)] : wb[min_c(kk, 2)];
+            const f2 bias = br == 0 ? bc : br == 1 ? bo : bb;
+            P.v[br] = fma2(wgt, xi, kk == 0 ? bias : P.v[br]);
+        } else if constexpr (op < 15) {
+            P.v[op - 12] = relu2(P.v[op - 12]);
+        } else {
+            constexpr int qq = op - 15, step = qq / 3, br = qq % 3;
+            if constexpr (step == 0) P.pk[br] = pk_f16(P.v[br]);
+            else if constexpr (step == 1) *reinterpret_cast<unsigned *>(dst + br * 2 * H) = P.pk[br];
+            else if constexpr (step == 2) P.hi[br] = unpk_f16(P.pk[br]);
+            else if constexpr (step == 3) P.v[br] = sub2(P.v[br], P.hi[br]);
+            else if constexpr (step == 4) P.v[br] = scale2(P.v[br], kH3LoScale);
+            else if constexpr (step == 5) P.pk[br] = pk_f16(P.v[br]);
+            else *reinterpret_cast<unsigned *>(dst + PLANE + br * 2 * H) = P.pk[br];
+        }
+        if constexpr (op == kLoadAtom) { if (pp + 1 < PPT) load_x(xbuf, pp + 1, P); }
+    };
+    auto produce_pair = [&](Prod &P, int xbuf, int abuf, int pp) {       // all of it at once (prologue)
+        static_for<kMicro>([&](auto opc) { micro(P, opc, xbuf, abuf, pp); });
+    };
+
+    // ---- prologue
+    uint2 rec_n;
+    bool rec_ok;
+    float4 oa[3], ob[3];
+    {
+        load_rec(blockIdx.x, rec_n, rec_ok);
+        load_obs(rec_n, rec_ok, oa, ob);
+        stash(0, oa, ob);
+        load_rec(blockIdx.x + G, rec_n, rec_ok);
+        load_obs(rec_n, rec_ok, oa, ob);
+        __syncthreads();
+        Prod P0;
+        load_x(0, 0, P0);
+#pragma unroll 2
+        for (int pp = 0; pp < PPT; ++pp) produce_pair(P0, 0, 0, pp);
+        stash(1, oa, ob);
+        load_rec(blockIdx.x + 2 * G, rec_n, rec_ok);
+        load_obs(rec_n, rec_ok, oa, ob);
+        load_rec(blockIdx.x + 3 * G, rec_n, rec_ok);
+        __syncthreads();
+    }
+
+    // ReLU, fc2 (PMINet.py:60-61) of a finished tile: as in pmi_score_x6_kernel, with the two orders combined first
+    auto epi_piece = [&](const f32x16 &ah, const f32x16 &al, float (&ev)[2], auto ec, float *pc) {
+        constexpr int e = decltype(ec)::value, st = e % 6;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = 2 * (e / 6) + u;
+            if constexpr (st == 0) ev[u] = __int_as_float(max(__float_as_int(fmaf(al[r], kH3LoInv, ah[r])), 0)) * wout;
+            else if constexpr (st == 1) ev[u] = dpp_add<0xB1>(ev[u]);
+            else if constexpr (st == 2) ev[u] = dpp_add<0x4E>(ev[u]);
+            else if constexpr (st == 3) ev[u] = dpp_add<0x141>(ev[u]);
+            else if constexpr (st == 4) ev[u] = dpp_add<0x140>(ev[u]);
+            else pc[(r & 3) + 8 * (r >> 2)] = ev[u];
+        }
+    };
+    auto partial_base = [&](int buf) {       // writer: lane 0 of each 16-lane row
+        return (lane & 15) == 0 ? part + buf * NW * 64 + w * 64 + ((lane >> 4) & 1) * 32 + 4 * kh : sink + w * 96 + lane;
+    };
+    const int ft = tid - (NW - 1) * 64;
+    auto final_sum = [&](unsigned tile, const float *pc) {      // over the column blocks, in order
+        if (ft >= 0 && ft < 32 && tile * 32 + ft < npairs) {
+            float sc = b2;
+#pragma unroll
+            for (int ww = 0; ww < 2 * NW; ++ww) sc += pc[ww * 32 + ft];
+            q.scores[tile * 32 + ft] = sc;
+        }
+    };
+
+    int cur = 0;
+    bool have_prev = false;
+    f32x16 accph, accpl;                     // the previous tile's accumulators: their epilogue runs under this tile's MFMAs
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accph[r] = 0.0f; accpl[r] = 0.0f; }
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += G) {
+        f32x16 acch = biasv, accl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accl[r] = 0.0f;
+        const unsigned char *afrag = aplanes + cur * NP * PLANE + afrag0;
+        auto load_a = [&](int s, u32x4 &h, u32x4 &l) {
+            h = *reinterpret_cast<const u32x4 *>(afrag + 0 * PLANE + s * 32);
+            l = *reinterpret_cast<const u32x4 *>(afrag + 1 * PLANE + s * 32);
+        };
+        Prod P;
+        load_x(cur ^ 1, 0, P);
+        float ev[2] = {0.0f, 0.0f};
+        float *pcp = partial_base(cur ^ 1);
+        u32x4 fh, fl, gh, gl;                 // this k-step's fragments, the next one's
+        load_a(0, fh, fl);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<KS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            constexpr int pp = s * PPT / KS;
+            constexpr int s0 = (pp * KS + PPT - 1) / PPT, s1 = ((pp + 1) * KS + PPT - 1) / PPT;   // first k-step of pp, of pp + 1
+            constexpr int nslot = 3 * (s1 - s0);
+            static_for<3>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int slot = 3 * (s - s0) + t;
+                constexpr int lo = slot * kMicro / nslot, hi = (slot + 1) * kMicro / nslot;
+                // small terms first: lo += Ah Bl, lo += Al Bh, hi += Ah Bh -- two accumulation chains
+                const f16x8 a = as_f16x8(t == 1 ? fl : fh);
+                const f16x8 bq = as_f16x8(t == 0 ? Bl[s] : Bh[s]);
+                if constexpr (t == 2) acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, acch, 0, 0, 0);
+                else accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, accl, 0, 0, 0);
+                if constexpr (t == 0 && s + 1 < KS) load_a(s + 1, gh, gl);
+                static_for<kMicro>([&](auto opc) {
+                    if constexpr (decltype(opc)::value >= lo && decltype(opc)::value < hi) micro(P, opc, cur ^ 1, cur ^ 1, pp);
+                });
+                constexpr int gslot = 3 * s + t;
+                constexpr int elo = gslot * 48 / (3 * KS), ehi = (gslot + 1) * 48 / (3 * KS);
+                static_for<48>([&](auto ec) {
+                    if constexpr (decltype(ec)::value >= elo && decltype(ec)::value < ehi) epi_piece(accph, accpl, ev, ec, pcp);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            fh = gh; fl = gl;
+        });
+
+        stash(cur, oa, ob);                                   // x of tile + 2 G (observations requested an iteration ago)
+        load_obs(rec_n, rec_ok, oa, ob);                      // tile + 3 G (record requested an iteration ago)
+        load_rec(tile + 4 * G, rec_n, rec_ok);
+        UAVTRACK_LDS_BARRIER();
+        if (have_prev) final_sum(tile - G, part + (cur ^ 1) * NW * 64);
+        accph = acch; accpl = accl;
+        have_prev = true;
+        cur ^= 1;
+    }
+    if (have_prev) {                         // the last tile's epilogue has nothing left to hide behind
+        float ev[2] = {0.0f, 0.0f};
+        float *pcp = partial_base(cur ^ 1);
+        static_for<48>([&](auto ec) { epi_piece(accph, accpl, ev, ec, pcp); });
+        __syncthreads();
+        const unsigned last = blockIdx.x + ((ntiles - 1 - blockIdx.x) / G) * G;
+        final_sum(last, part + (cur ^ 1) * NW * 64);
+    }
+}
+
 struct MixParams {
     const uint32_t *nbrec;       // [S][B][N][W + 2] neighbour records of the chunk's S steps
     const float *scores;         // one per pair
     float *reward;               // [S][B][N]
+    float *rsum;                 // [S][B] mean over the UAVs of the final reward (nullable): what the episode sum adds up
     unsigned *pair_count;        // reset here for the next chunk's pair emission
     int32_t SB, N, E;            // SB = S * B "virtual environments"
     float coop;
@@ -618,11 +904,12 @@ __global__ void __launch_bounds__(kMaxWorkgroup) pmi_mix_kernel(const MixParams 
             for (int w = 0; w < RS; ++w) mix_lds[(size_t)tid * RS + w] = f.nbrec[gid * RS + w];
     }
     __syncthreads();
-    if (!active) return;
+    float r = 0.0f;
+    if (active) {
     const uint32_t *env_rec = mix_lds + (size_t)e * N * RS;
     const uint32_t *me = env_rec + (size_t)i * RS;
     const float raw_i = __uint_as_float(me[W + 1]);
-    float r = (1.0f - f.coop) * raw_i;                                 // uav.py:290
+    r = (1.0f - f.coop) * raw_i;                                       // uav.py:290
     if (SMALL) {
         const unsigned long long mask = (unsigned long long)me[0] | ((unsigned long long)me[1] << 32);
         if (mask) {
@@ -668,60 +955,33 @@ __global__ void __launch_bounds__(kMaxWorkgroup) pmi_mix_kernel(const MixParams 
             r = fmaf(f.coop, num / den, r);
         }
     }
-    f.reward[gid] = fminf(fmaxf(r, -1.0f), 1.0f);                    // environment.py:225
+    r = fminf(fmaxf(r, -1.0f), 1.0f);                                // environment.py:225
+    f.reward[gid] = r;
+    }
+    if (f.rsum) {      // mean over the instance's UAVs, fixed order (train.py:181: the episode return adds these up over t)
+        __syncthreads();                                   // everyone is done with the staged records
+        float *rl = reinterpret_cast<float *>(mix_lds);
+        if (active) rl[tid] = r;
+        __syncthreads();
+        if (active && i == 0) {
+            float sum = 0.0f;
+            for (int j = 0; j < N; ++j) sum += rl[e * N + j];
+            f.rsum[env0 + e] = sum * (1.0f / (float)N);
+        }
+    }
 }
 
-// train.py:181-192 accumulators for the MAAC-R path, from the chunk's outputs (the fused kernel keeps
-// them in registers for the other reward modes).  One lane per UAV, fixed-order reductions.
-struct EpParams {
-    const float *reward, *terms;     // [S][B][N], [S][3][B][N] (terms nullable)
-    const int32_t *covered;          // [S][B] (nullable)
-    float *ep_sums;                  // [B][5]
-    int32_t S, B, N, E, add, K;      // K: lanes (step slices) per UAV
-};
-
-// Episode sums of a chunk (train.py:181-192).  K lanes per (environment, UAV), each summing every K-th
-// step; the slices, then the UAVs, are added in a fixed order (bitwise reproducible).  (One lane per UAV walking all
-// S steps left the chip mostly idle: 342 workgroups of dependent loads, 93 us per 100-step chunk at 4096 x 20.)
-constexpr int kEpSlices = 4;      // K for swarms of up to kMaxWorkgroup / 4 UAVs (launch_ep_sums)
-__global__ void __launch_bounds__(kMaxWorkgroup) ep_sums_kernel(const EpParams q)
+// MAAC-R episode return (train.py:181-182): ep_sums[b][0] (+)= sum over the chunk's steps of the per-step mean reward
+// the mix kernel left in rsum [S][B]; one lane per environment, steps in order.  (The other four sums are the rollout
+// kernel's, as in the other reward modes.)
+__global__ void __launch_bounds__(256) ep_reward_kernel(const float *__restrict__ rsum, float *__restrict__ ep_sums, int S, int B, int add)
 {
-    extern __shared__ float4 red4[];                 // [E * N][K]
-    const int K = q.K;
-    const int tid = threadIdx.x, N = q.N;
-    const int env0 = blockIdx.x * q.E;
-    const int envs_here = min(q.E, q.B - env0);
-    const int sl = tid % K, ag = tid / K;            // slice, (environment, UAV) of this lane
-    const int e = ag / N, i = ag - e * N;
-    const bool active = ag < q.E * N && e < envs_here;
-    const size_t BN = (size_t)q.B * N, g = (size_t)(env0 + e) * N + i;
-    float4 acc = make_float4(0, 0, 0, 0);
-    if (active) {
-        for (int t = sl; t < q.S; t += K) {
-            acc.x += q.reward[(size_t)t * BN + g];
-            if (q.terms) {
-                const float *tp = q.terms + (size_t)t * 3 * BN + g;
-                acc.y += tp[0]; acc.z += tp[BN]; acc.w += tp[2 * BN];
-            }
-        }
-        red4[tid] = acc;
-    }
-    __syncthreads();
-    if (active && i == 0 && sl == 0) {
-        float4 s = make_float4(0, 0, 0, 0);
-        for (int j = 0; j < N; ++j)
-            for (int k = 0; k < K; ++k) {
-                const float4 v = red4[(e * N + j) * K + k];
-                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-            }
-        float cov = 0.0f;
-        if (q.covered)
-            for (int t = 0; t < q.S; ++t) cov += (float)q.covered[(size_t)t * q.B + env0 + e];
-        const float inv = 1.0f / (float)N;
-        float *ep = q.ep_sums + (size_t)(env0 + e) * 5;
-        if (q.add) { ep[0] += s.x * inv; ep[1] += s.y * inv; ep[2] += s.z * inv; ep[3] += s.w * inv; ep[4] += cov; }
-        else       { ep[0] = s.x * inv;  ep[1] = s.y * inv;  ep[2] = s.z * inv;  ep[3] = s.w * inv;  ep[4] = cov; }
-    }
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    float s = 0.0f;
+    for (int t = 0; t < S; ++t) s += rsum[(size_t)t * B + b];
+    float *ep = ep_sums + (size_t)b * 5;
+    if (add) ep[0] += s; else ep[0] = s;
 }
 
 }  // namespace
@@ -785,6 +1045,27 @@ __global__ void __launch_bounds__(256) pmi_inference_prep_kernel(const float4 *_
     pairs[k] = make_uint2(2u * k, 1u);
 }
 
+// fc1 as two f16 planes in the B-operand order of v_mfma_f32_32x32x16_f16 (same element order as pack_pmi_x6):
+// plane 0 = f16(w) (round to nearest), plane 1 = f16((w - plane 0) * 2^11).
+void pack_pmi_h3(const float *abi_blob, uint16_t *planes, int H)
+{
+    const int K = 3 * H, KS = K / 16, NW = H / 32;
+    const float *W1 = abi_blob + (size_t)15 * H;
+    for (int w = 0; w < NW; ++w)
+        for (int s = 0; s < KS; ++s)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const float v = W1[(size_t)(16 * s + 8 * (l >> 5) + j) * H + w * 32 + (l & 31)];
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
+                    uint16_t bh, bl;
+                    memcpy(&bh, &hi, 2);
+                    memcpy(&bl, &lo, 2);
+                    planes[((((size_t)w * 2 + 0) * KS + s) * 64 + l) * 8 + j] = bh;
+                    planes[((((size_t)w * 2 + 1) * KS + s) * 64 + l) * 8 + j] = bl;
+                }
+}
+
 hipError_t launch_pmi_inference_prep(const float *x, float *obs2, uint2 *pairs, unsigned n, hipStream_t stream)
 {
     hipLaunchKernelGGL(pmi_inference_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, stream,
@@ -797,6 +1078,7 @@ hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream
     PmiParams q;
     q.blob = env->pmi.blob;
     q.x6 = env->pmi.x6;
+    q.h3 = env->pmi.h3;
     q.obs = obs;
     q.pairs = pairs ? pairs : env->pairs;
     q.pair_count = env->pair_count;
@@ -812,7 +1094,29 @@ hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream
     // Widths up to kPmiX6MaxHidden run the layer as six bf16 MFMAs per k-step (pmi_score_x6_kernel): one persistent
     // workgroup per CU.  UAVTRACK_PMI_FP32=1 keeps the fp32-MFMA kernel (A/B measurements, and the wider layers).
     static const bool force_fp32 = [] { const char *s = getenv("UAVTRACK_PMI_FP32"); return s && atoi(s) != 0; }();
-    if (q.x6 && !force_fp32) {
+    // UAVTRACK_PMI_SCHEME = h3 | x6 | fp32 (A/B measurements); default: f16 x 3 where the weights allow it (see
+    // uavtrack_set_pmi_weights), else bf16 x 6, else the fp32-MFMA kernel
+    static const int scheme = [] {
+        const char *s = getenv("UAVTRACK_PMI_SCHEME");
+        return !s ? 0 : !strcmp(s, "h3") ? 1 : !strcmp(s, "x6") ? 2 : !strcmp(s, "fp32") ? 3 : 0;
+    }();
+    if (q.h3 && !force_fp32 && (scheme == 0 || scheme == 1)) {
+        // H = 128 / 96: one workgroup per CU, one wavefront per SIMD.  H = 64: a workgroup is two wavefronts and 52 KB of LDS
+        static const int mult64h = [] {
+            const char *e = getenv("UAVTRACK_H3_GRID64");
+            const int v = e ? atoi(e) : 2;
+            return v < 1 ? 1 : (v > 4 ? 4 : v);
+        }();
+        const int grid3 = (env->n_cus > 0 ? env->n_cus : 256) * (env->pmi.hidden <= 64 ? mult64h : 1);
+        switch (env->pmi.hidden) {
+#define UAVTRACK_PMI_CASE(HH) case HH: hipLaunchKernelGGL(pmi_score_h3_kernel<HH>, dim3(grid3), dim3(2 * HH), 0, stream, q); break;
+            UAVTRACK_PMI_CASE(64) UAVTRACK_PMI_CASE(96) UAVTRACK_PMI_CASE(128)
+#undef UAVTRACK_PMI_CASE
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
+    if (q.x6 && !force_fp32 && scheme != 3) {
         // one workgroup per CU at H = 96 / 128 (3 - 4 wavefronts, one per SIMD); at H = 64 a workgroup is two wavefronts and
         // 81 KB of LDS, so two of them share a CU and fill its four SIMDs
         static const int mult64 = [] {
@@ -840,11 +1144,11 @@ hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream
     return hipGetLastError();
 }
 
-hipError_t launch_pmi_finalize(const uavtrack_env *env, int steps, float *reward, hipStream_t stream)
+hipError_t launch_pmi_finalize(const uavtrack_env *env, int steps, float *reward, float *rsum, hipStream_t stream)
 {
     const uavtrack_config &c = env->cfg;
     MixParams f;
-    f.nbrec = env->nbrec; f.scores = env->scores; f.reward = reward;
+    f.nbrec = env->nbrec; f.scores = env->scores; f.reward = reward; f.rsum = rsum;
     f.pair_count = env->pair_count;
     // one lane per UAV-step (the rollout kernel's geometry is its own)
     const int wgs = c.n_uav <= 256 ? 256 : kMaxWorkgroup;
@@ -859,17 +1163,10 @@ hipError_t launch_pmi_finalize(const uavtrack_env *env, int steps, float *reward
     return hipGetLastError();
 }
 
-hipError_t launch_ep_sums(const uavtrack_env *env, int steps, const float *reward, const float *terms,
-                          const int32_t *covered, float *ep_sums, bool add, hipStream_t stream)
+hipError_t launch_ep_reward(const uavtrack_env *env, int steps, const float *rsum, float *ep_sums, bool add, hipStream_t stream)
 {
-    const uavtrack_config &c = env->cfg;
-    // kEpSlices lanes per UAV where a workgroup has them, fewer for the largest swarms
-    int K = kEpSlices;
-    while (K > 1 && c.n_uav * K > kMaxWorkgroup) K >>= 1;
-    const int wgs = c.n_uav * K <= 256 ? 256 : kMaxWorkgroup;
-    EpParams q{reward, terms, covered, ep_sums, steps, c.n_envs, c.n_uav, wgs / (c.n_uav * K), add ? 1 : 0, K};
-    const size_t lds = (size_t)q.E * q.N * K * 16;
-    hipLaunchKernelGGL(ep_sums_kernel, dim3((unsigned)((c.n_envs + q.E - 1) / q.E)), dim3(wgs), lds, stream, q);
+    const int B = env->cfg.n_envs;
+    hipLaunchKernelGGL(ep_reward_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, rsum, ep_sums, steps, B, add ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -423,8 +423,14 @@ __device__ __forceinline__ void sweep_weighted(const StepParams &p, int N, int M
 // EXTRAS: the launch uses the rarely wanted per-step extras (target trace, automatic reset); compiled out otherwise --
 // their tests and parameters cost the plain rollout ~10 % when they sat in the same instantiation.
 // LONE: built for single-wavefront workgroups on a grid of at most a few waves per SIMD (plan_geometry's small grid).
+// (experiments only: -DUAVTRACK_WAVES_PER_EU=n asks the register allocator for n resident waves per SIMD)
+#ifdef UAVTRACK_WAVES_PER_EU
+#define UAVTRACK_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(UAVTRACK_WAVES_PER_EU)))
+#else
+#define UAVTRACK_OCCUPANCY_ATTR
+#endif
 template <int N_, int M_, int MODE, bool Z3, int POLICY, bool ALLOUT = false, bool EXTRAS = false, bool LONE = false>
-__global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams p)
+__global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout_kernel(const StepParams p)
 {
     constexpr bool GREEDY = POLICY == kPolicyGreedy;
     constexpr bool ACTOR = POLICY == kPolicyActor;
@@ -1057,11 +1063,16 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             }
             const float inv_n = 1.0f / (float)N;
             float *ep = p.ep_sums + (size_t)b * 5;
+            // (MAAC-R: the reward is final only behind the scorer; its episode sum comes from the mix stage, pmi_kernel.hip.
+            // The three terms and the coverage do not depend on the scores and are summed here as in the other modes.)
+            constexpr bool kReward = MODE != UAVTRACK_REWARD_PMI;
             if (p.ep_accumulate) {
-                ep[0] += sum.x * inv_n; ep[1] += sum.y * inv_n; ep[2] += sum.z * inv_n; ep[3] += sum.w * inv_n;
+                if (kReward) ep[0] += sum.x * inv_n;
+                ep[1] += sum.y * inv_n; ep[2] += sum.z * inv_n; ep[3] += sum.w * inv_n;
                 ep[4] += (float)ecov;
             } else {
-                ep[0] = sum.x * inv_n; ep[1] = sum.y * inv_n; ep[2] = sum.z * inv_n; ep[3] = sum.w * inv_n;
+                if (kReward) ep[0] = sum.x * inv_n;
+                ep[1] = sum.y * inv_n; ep[2] = sum.z * inv_n; ep[3] = sum.w * inv_n;
                 ep[4] = (float)ecov;
             }
         }
@@ -1117,12 +1128,18 @@ KernelFn pick_kernel(int N, int M, int mode, bool z3, int *specialised, int poli
                      bool extras = false, bool lone = false)
 {
     *specialised = 1;
+#ifdef UAVTRACK_ONLY_SHAPE_N     // experiment builds (tools/build_variant.sh): one shape only, a fraction of the compile time
+    if (N == UAVTRACK_ONLY_SHAPE_N && M == UAVTRACK_ONLY_SHAPE_M)
+        return pick_mode<UAVTRACK_ONLY_SHAPE_N, UAVTRACK_ONLY_SHAPE_M>(mode, z3, policy, allout, extras, lone);
+    return nullptr;
+#else
     if (N == 20 && M == 10) return pick_mode<20, 10>(mode, z3, policy, allout, extras, lone);
     if (N == 50 && M == 25) return pick_mode<50, 25>(mode, z3, policy, allout, extras, lone);
     if (N == 10 && M == 10) return pick_mode<10, 10>(mode, z3, policy, allout, extras, lone);
     if (N == 5 && M == 3) return pick_mode<5, 3>(mode, z3, policy, allout, extras, lone);
     *specialised = 0;
     return pick_mode<0, 0>(mode, z3, policy, allout, extras, lone);
+#endif
 }
 
 }  // namespace
