@@ -112,6 +112,9 @@ int validate(const uavtrack_config &c)
     if (c.nc < 1 || c.nc > UAVTRACK_MAX_CLIMB) return fail("nc must be in [1, %d] (got %d)", UAVTRACK_MAX_CLIMB, c.nc);
     if (c.dim == 2 && c.nc != 1) return fail("nc must be 1 when dim == 2 (got %d)", c.nc);
     if (c.norm_n_uav < 1 || c.norm_m_targets < 1) return fail("norm_n_uav / norm_m_targets must be >= 1");
+    // swarms of up to 64 UAVs count neighbours in the high part of an exact fp32 integer sum (step_kernel.hip act_bias_shape)
+    if (c.n_uav <= 64 && (int64_t)c.n_uav * c.n_uav * c.na * c.nc * 4 >= ((int64_t)1 << 24))
+        return fail("na * nc = %d actions is beyond what a swarm of %d UAVs supports (n_uav^2 * na * nc must stay below 2^22)", c.na * c.nc, c.n_uav);
     if (c.reward_mode < UAVTRACK_REWARD_RAW || c.reward_mode > UAVTRACK_REWARD_PMI)
         return fail("reward_mode must be 0 (raw), 1 (mean) or 2 (pmi) (got %d)", c.reward_mode);
     if (c.horizon < 0) return fail("horizon must be >= 0");
@@ -196,6 +199,13 @@ void fold_constants(const uavtrack_config &c, StepParams &p, float *climb_c, flo
     }
     p.vratio = (float)(c.t_v_max / c.u_v_max);
     p.inv_na_total = (float)(1.0 / (double)(c.na * c.nc));
+    p.inv_na = (float)(1.0 / (double)c.na);
+    {   // act_bias_shape() (step_kernel.hip): K = 2^k > n_uav * na * nc; validate() keeps n_uav * (K + na * nc) < 2^24 where it is used
+        int k = 1;
+        while ((int64_t)1 << k <= (int64_t)c.n_uav * c.na * c.nc && k < 30) ++k;
+        p.act_bias = std::ldexp(1.0f, k);
+        p.inv_act_bias = std::ldexp(1.0f, -k);
+    }
     const double log2e = 1.4426950408889634;
     p.exp_k0 = (float)log2e;
     p.exp_k1 = (float)(log2e / (2.0 * c.dp));

@@ -93,6 +93,8 @@ struct StepParams {
     float lt_dp2;                                     // strict form: K * S  (d2 < K)
     float vratio;                // target.v_max / uav.v_max      (uav.py:116)
     float inv_na_total;
+    float inv_na;                // 1 / na: the climb index of a 3-D action is floor((a + 0.5) / na)
+    float act_bias, inv_act_bias;   // step_kernel.hip act_bias_shape(): K, a power of two above n_uav * na * nc, and 1 / K
     float exp_k0, exp_k1;        // exp((2dp-d)/(2dp)) = exp2(k0 - k1*d)   (uav.py:226)
     float tt_ceil, inv_tt_ceil;  // 2*m_targets                   (environment.py:208)
     float dup_floor, inv_dup;    // -e/2*n_uav and 1/(e/2*n_uav)  (environment.py:210)

@@ -972,16 +972,27 @@ __global__ void __launch_bounds__(kMaxWorkgroup) pmi_mix_kernel(const MixParams 
 }
 
 // MAAC-R episode return (train.py:181-182): ep_sums[b][0] (+)= sum over the chunk's steps of the per-step mean reward
-// the mix kernel left in rsum [S][B]; one lane per environment, steps in order.  (The other four sums are the rollout
-// kernel's, as in the other reward modes.)
+// the mix kernel left in rsum [S][B].  16 lanes per environment, each summing every 16th step (coalesced across the
+// environments); the slices are then added in a fixed order (bitwise reproducible).  (The other four sums are the
+// rollout kernel's, as in the other reward modes.)
+constexpr int kEpSlices = 16;
 __global__ void __launch_bounds__(256) ep_reward_kernel(const float *__restrict__ rsum, float *__restrict__ ep_sums, int S, int B, int add)
 {
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= B) return;
+    __shared__ float red[256];
+    const int el = threadIdx.x % 16, sl = threadIdx.x / 16;          // environment within the block, step slice
+    const int b = blockIdx.x * 16 + el;
     float s = 0.0f;
-    for (int t = 0; t < S; ++t) s += rsum[(size_t)t * B + b];
-    float *ep = ep_sums + (size_t)b * 5;
-    if (add) ep[0] += s; else ep[0] = s;
+    if (b < B)
+        for (int t = sl; t < S; t += kEpSlices) s += rsum[(size_t)t * B + b];
+    red[sl * 16 + el] = s;
+    __syncthreads();
+    if (sl == 0 && b < B) {
+        float tot = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kEpSlices; ++k) tot += red[k * 16 + el];
+        float *ep = ep_sums + (size_t)b * 5;
+        if (add) ep[0] += tot; else ep[0] = tot;
+    }
 }
 
 }  // namespace
@@ -1166,7 +1177,7 @@ hipError_t launch_pmi_finalize(const uavtrack_env *env, int steps, float *reward
 hipError_t launch_ep_reward(const uavtrack_env *env, int steps, const float *rsum, float *ep_sums, bool add, hipStream_t stream)
 {
     const int B = env->cfg.n_envs;
-    hipLaunchKernelGGL(ep_reward_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, rsum, ep_sums, steps, B, add ? 1 : 0);
+    hipLaunchKernelGGL(ep_reward_kernel, dim3((unsigned)((B + 15) / 16)), dim3(256), 0, stream, rsum, ep_sums, steps, B, add ? 1 : 0);
     return hipGetLastError();
 }
 

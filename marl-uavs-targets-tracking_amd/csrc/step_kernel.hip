@@ -55,6 +55,12 @@
 #ifndef UAVTRACK_UNROLL_T
 #define UAVTRACK_UNROLL_T 5
 #endif
+#ifndef UAVTRACK_FULL_BARRIER      // 0: the two step barriers order LDS only (s_waitcnt lgkmcnt(0); s_barrier) -- measured neutral
+#define UAVTRACK_FULL_BARRIER 1
+#endif
+#ifndef UAVTRACK_KNOCKOUT_BARRIER  // timing experiments only (results are racy): 1 drops the second step barrier, 2 both
+#define UAVTRACK_KNOCKOUT_BARRIER 0
+#endif
 
 namespace uavtrack {
 
@@ -163,8 +169,12 @@ __device__ __forceinline__ void sincos_any(float h, float *s, float *c)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       \
             __builtin_amdgcn_wave_barrier();                             \
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
-        } else {                                                         \
+        } else if (UAVTRACK_FULL_BARRIER) {                              \
             __syncthreads();                                             \
+        } else {                                                         \
+            /* LDS-only: __syncthreads() also drains vmcnt, i.e. every wave would wait here for its own output stores   \
+               of the previous step to land in memory -- nothing on this path is ordered through global memory */         \
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                              \
         }                                                                \
     } while (0)
 
@@ -209,6 +219,12 @@ __device__ __forceinline__ void uav_store(float4 *rows, int j, float x, float y,
     f[b] = x; f[2 + b] = y; f[4 + b] = c; f[6 + b] = s; f[8 + b] = a; f[10 + b] = z;
 }
 
+// Specialised swarms of up to 64 UAVs keep `action + K` in the table's action slot, K = StepParams::act_bias a power of
+// two above n_uav * na * nc: the peer sweep's sum of (mask * slot) then carries the neighbour COUNT in its high part and the
+// action sum in its low part, both exact integers in fp32, and the count needs no accumulator of its own (one packed add
+// less per peer pair).  fold_constants / uavtrack_create keep n_uav * (K + na * nc) below 2^24 for these shapes.
+__device__ __host__ constexpr bool act_bias_shape(int n_spec) { return n_spec > 0 && n_spec <= 64; }
+
 // ---------------------------------------------------------------------------------------
 // Pair sweeps of one UAV, fast path: two agents per packed instruction, no per-agent
 // `j != i` test (self terms are subtracted afterwards).  The uav.py:165/179 weight is 1
@@ -224,6 +240,7 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
 {
     const v2f xi2 = splat(xi), yi2 = splat(yi), zi2 = splat(zi);
     const v2f nscale = splat(p.le_neg_scale);
+    constexpr bool kActBias = act_bias_shape(N_);
     const int NP = pairs_of(N_ > 0 ? N_ : N), MP = pairs_of(M_ > 0 ? M_ : M);
     // Up to 10 pair rows (N <= 20) the whole peer sweep is unrolled: measured 4-7 % faster than
     // unrolling by 5 and, with the pair layout, still 127 VGPRs; larger N keeps the partial unroll.
@@ -325,7 +342,7 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
         sc = pk_fma(mm, (v2f){m1.x, m1.y}, sc);
         ss = pk_fma(mm, (v2f){m1.z, m1.w}, ss);
         sa = pk_fma(mm, (v2f){m2.x, m2.y}, sa);
-        cnt += mm;
+        if (!kActBias) cnt += mm;
     }
     if (NBF) {   // Horner left pair jp at digit NP-1-jp: slot 1 into the even bits, reverse, align -> bit j = UAV j
         const unsigned w = (unsigned)nbf.y | ((unsigned)nbf.x << 1);
@@ -339,13 +356,18 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
     if (Z3) { const float dzs = odd ? 0.0f : zo - zi; d2s = fmaf(dzs, dzs, d2s); }
     const float ms = (d2s <= p.dc2) ? 1.0f : 0.0f;
     a.dup = dup.x + dup.y - fast_exp2(p.exp_k0);
-    a.cntU = cnt.x + cnt.y - ms; a.iwU = a.cntU;
+    float cnt_all = cnt.x + cnt.y, sa_all = sa.x + sa.y;
+    if (kActBias) {   // the table's action slot holds a + K: sum m (a + K) = K * count + sum m a, both exact small integers
+        cnt_all = floorf(sa_all * p.inv_act_bias);
+        sa_all = fmaf(-p.act_bias, cnt_all, sa_all);
+    }
+    a.cntU = cnt_all - ms; a.iwU = a.cntU;
     a.sxU = sx.x + sx.y - ms * dxs;
     a.syU = sy.x + sy.y - ms * dys;
     // sum_j m (c_j - c_i) = sum_j m c_j - c_i cnt
     a.scU = fmaf(-ci, a.cntU, sc.x + sc.y - ms * (odd ? ci : co));
     a.ssU = fmaf(-si, a.cntU, ss.x + ss.y - ms * (odd ? si : so));
-    a.saU = fmaf(-ai, a.cntU, sa.x + sa.y - ms * (odd ? ai : ao));
+    a.saU = fmaf(-ai, a.cntU, sa_all - ms * (odd ? ai : ao));
 }
 
 // Literal form with the uav.py:165/179 weight min(dist((rel_x, rel_y), (abs_x, abs_y)), 1).
@@ -357,7 +379,7 @@ __device__ __forceinline__ void sweep_weighted(const StepParams &p, int N, int M
                                                const float4 *__restrict__ rowNew, const float4 *__restrict__ rowOld,
                                                const float4 *__restrict__ trow, const v2f *__restrict__ tzrow,
                                                unsigned *__restrict__ covw, int covbase,
-                                               float xi, float yi, float zi, float ci, float si, float ai, Acc &a)
+                                               float xi, float yi, float zi, float ci, float si, float ai, float abias, Acc &a)
 {
     a = Acc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned bits = 0;
@@ -410,7 +432,7 @@ __device__ __forceinline__ void sweep_weighted(const StepParams &p, int N, int M
         const float iw = inm ? 1.0f / fminf(sqrtf(rx * rx + ry * ry), 1.0f) : 0.0f;
         a.scU = fmaf(iw, mx.c - ci, a.scU);
         a.ssU = fmaf(iw, mx.s - si, a.ssU);
-        a.saU = fmaf(iw, mx.a - ai, a.saU);
+        a.saU = fmaf(iw, (mx.a - abias) - ai, a.saU);
         a.cntU += m;
         a.iwU += iw;
         a.sxU = fmaf(iw, dxm, a.sxU);
@@ -444,6 +466,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
     const int EN = E * N;
     const int CW = cov_words(M);
     const int MP = pairs_of(M);
+    const float abias = act_bias_shape(N_) ? p.act_bias : 0.0f;     // what the table's action slot holds beside the action
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;
 
@@ -458,6 +481,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
     int *ncnt = reinterpret_cast<int *>(fb);  fb += E * M;   // [E][M] UAVs within dc of a target (greedy policy)
     unsigned *covw = reinterpret_cast<unsigned *>(fb);   // [2][E * CW] (+ 2 words, MAAC-R pair emission; + E words, automatic reset)
     unsigned *rstw = covw + 2 * E * CW + 2;              // [E] 0, or 1 + the episode number an environment is being reset to
+    float *climb_l = reinterpret_cast<float *>(rstw + E); // (3-D) [2][UAVTRACK_MAX_CLIMB] cos / sin of the climb angles
 
     const int grp = xcd_group(blockIdx.x, gridDim.x);
     const int env0 = grp * E;
@@ -481,13 +505,14 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
 
     // ---- load state once
     const StateBlock S = state_view(p.slab, p.B, N, M, Z3);
+    if (Z3 && tid < 2 * UAVTRACK_MAX_CLIMB) climb_l[tid] = S.climb_c[tid];      // (climb_s follows climb_c in the slab)
     if (active) {
         x = S.ux[g]; y = S.uy[g]; h = S.uh[g]; a_prev = S.ua[g];
         if (Z3) z = S.uz[g];
         sincos_any(h, &s, &c);
         count = S.step_count[b];
         if (EXTRAS) epi = S.episode[b];
-        uav_store(uenv + 3, i, x, y, c, s, (float)a_prev, z);            // "previous" copy (1) for step 0
+        uav_store(uenv + 3, i, x, y, c, s, (float)a_prev + abias, z);    // "previous" copy (1) for step 0
         if ((N & 1) && i == N - 1) {                                      // padding agent of the last pair
             uav_store(uenv, N, kFar, kFar, 0.f, 0.f, 0.f, 0.f);
             uav_store(uenv + 3, N, kFar, kFar, 0.f, 0.f, 0.f, 0.f);
@@ -677,11 +702,12 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
         if (active) {
             a_now = GIVEN ? act : min(max(act, 0), p.na_total - 1);   // (given actions are clamped where they are loaded)
             int a_turn = a_now, a_climb = 0;
-            if (Z3) { a_climb = a_now / p.na; a_turn = a_now - a_climb * p.na; }
+            // (a / na through the float reciprocal: exact for these small integers, no integer-division sequence)
+            if (Z3) { a_climb = (int)(((float)a_now + 0.5f) * p.inv_na); a_turn = a_now - a_climb * p.na; }
             float step_xy = p.dtv_u;
-            if (Z3) {
-                step_xy = p.dtv_u * S.climb_c[a_climb];
-                z = fmaf(p.dtv_u, S.climb_s[a_climb], z);
+            if (Z3) {   // the climb-angle table sits in LDS (copied at launch start): no trip to L2 on every step
+                step_xy = p.dtv_u * climb_l[a_climb];
+                z = fmaf(p.dtv_u, climb_l[UAVTRACK_MAX_CLIMB + a_climb], z);
             }
             x = fmaf(step_xy, c, x);
             y = fmaf(step_xy, s, y);
@@ -690,13 +716,13 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
             ai = (float)a_now;
             {
                 float *f = own0 + pn * 12;                   // copy pn of this lane's pair row
-                f[0] = x; f[2] = y; f[4] = c; f[6] = s; f[8] = ai; f[10] = z;
+                f[0] = x; f[2] = y; f[4] = c; f[6] = s; f[8] = ai + abias; f[10] = z;
             }
             if (GIVEN && t + 1 < p.T) act_next = *at(p.actions + row + BN, g32 * 4u);   // prefetch next step's action
             if (i == 0)
                 for (int w = 0; w < CW; ++w) covw[cbuf + e * CW + w] = 0;
         }
-        UAVTRACK_STEP_BARRIER();
+        if (UAVTRACK_KNOCKOUT_BARRIER < 2) UAVTRACK_STEP_BARRIER();
 
         // ---- P2: pair sweeps
         float tt = 0, bp = 0, dupn = 0, raw = 0;
@@ -717,7 +743,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
             const bool near0 = fmaxf(fabsf(x), fabsf(y)) < 2.5f;
             if (__builtin_expect(near0, 0)) {
                 sweep_weighted<Z3>(p, N, M, i, rowNew, rowOld, tenv, tzrow, covw, cbuf + e * CW,
-                                   x, y, z, c, s, ai, acc);
+                                   x, y, z, c, s, ai, abias, acc);
                 if (kMask)
                     for (int j = 0; j < N; ++j) {
                         const UavRow nw = uav_elem(rowNew, j);
@@ -795,7 +821,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
             wg_cnt[0] = 0;
             if (t > 0) wg_cnt[1] = pe_base;
         }
-        UAVTRACK_STEP_BARRIER();
+        if (UAVTRACK_KNOCKOUT_BARRIER < 1) UAVTRACK_STEP_BARRIER();
 
         // ---- P4: cooperative reward, coverage, outputs
         if (active) {
@@ -977,7 +1003,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
                     a_prev = (int)(((uint64_t)r.v[1] * (uint32_t)p.na_total) >> 32);
                     sincos_any(h, &s, &c);
                     count = 0;
-                    uav_store(uenv + pn * 3, i, x, y, c, s, (float)a_prev, z);       // this step's copy: the next step's "previous" one
+                    uav_store(uenv + pn * 3, i, x, y, c, s, (float)a_prev + abias, z);   // this step's copy: the next step's "previous" one
                     o[0] = o[1] = o[2] = o[3] = o[4] = o[5] = o[6] = o[7] = o[8] = -1.0f;   // get_states() of a fresh state (uav.py:174,186)
                     o[9] = x * p.inv_dc; o[10] = y * p.inv_dc; o[11] = (float)a_prev * p.inv_na_total;
                 }
@@ -1083,7 +1109,8 @@ size_t lds_bytes_for(int E, int N, int M, bool z3)
 {
     const size_t CW = cov_words(M), MP = pairs_of(M);
     const size_t f4 = (size_t)E * ustride_of(N) + (size_t)E * tstride_of(M);
-    const size_t f = (size_t)E * M + (size_t)E * (N + 1) + (z3 ? (size_t)E * MP * 2 : 0) + (size_t)E * M + 2 * E * CW + 2 + E;
+    const size_t f = (size_t)E * M + (size_t)E * (N + 1) + (z3 ? (size_t)E * MP * 2 : 0) + (size_t)E * M + 2 * E * CW + 2 + E +
+                     (z3 ? 2 * UAVTRACK_MAX_CLIMB : 0);
     return (f4 * 16 + f * 4 + 15) & ~(size_t)15;   // ustride >= 3 N float4 per env, so ep_sums staging (E N float4) fits
 }
 
