@@ -610,19 +610,6 @@ def extras(uavtrack, args, B, device, bytes_unit):
         "ms_per_step_all_runs": [r["wall_s"] * 1e3 / k for r in runs],
         "note": "uavtrack_step eager from Python/ctypes, best of three 400-step runs; host-launch bound",
     }
-    # the T = 1 kernel's own duration (library-side HIP events around each launch; an event pair adds ~1-2 us of its own)
-    env = make_env(uavtrack, args, B, device)
-    g = torch.Generator(device=device).manual_seed(3)
-    acts = torch.randint(0, env.cfg.na_total, (B, N), dtype=torch.int32, device=device, generator=g)
-    env.reset(seed=args.seed)
-    for _ in range(300):
-        env.step(acts)
-    env.set_profiling(True)
-    for _ in range(200):
-        env.step(acts)
-    pr = env.profile()["rollout"]
-    env.close()
-    out["per_step_launch"]["kernel_us_per_step"] = pr["ms"] * 1e3 / max(pr["launches"], 1)
     # a batch that fills the chip (SURVEY 8d 'bandwidth-saturating batch'), measured like the roofline leg
     # (200-step launches like the headline leg when the 17 GB of outputs fit comfortably; 50-step launches otherwise --
     # they carry the kernel's start-up cost four times as often and read ~15 % lower)
@@ -641,11 +628,12 @@ def extras(uavtrack, args, B, device, bytes_unit):
     torch.manual_seed(args.seed)
     actor = uavtrack.ActorMLP(hidden_dim=128, action_dim=12 * (3 if args.dim == 3 else 1)).to(device)
     cl = {}
-    modes = ("eager", "graph", "actor_graph") + (("greedy_graph",) if args.dim == 2 else ())
+    modes = ("eager", "graph", "actor_graph", "actor_chunks") + (("greedy_graph", "greedy_chunks") if args.dim == 2 else ())
     for mode in modes:
         env = make_env(uavtrack, args, B, device)
-        ro = uavtrack.BatchedRollout(env, "greedy" if mode == "greedy_graph" else actor, steps_per_graph=10,
-                                     use_graph=(mode != "eager"), device_actor=(mode == "actor_graph"))
+        ro = uavtrack.BatchedRollout(env, "greedy" if mode.startswith("greedy") else actor, steps_per_graph=10,
+                                     use_graph=(mode != "eager"), device_actor=mode.startswith("actor"),
+                                     fuse_chunks=mode.endswith("chunks"))
         ro.reset(seed=args.seed)
         ro.run(40)
         torch.cuda.synchronize(device)
@@ -683,7 +671,8 @@ def extras(uavtrack, args, B, device, bytes_unit):
     cl["note"] = ("reference-shaped shared actor (FnnPolicyNet 12-128-12 softmax as in configs/MAAC.yaml, random "
                   "init) + categorical sample + uavtrack_step_accumulate, all on device; eager/graph = the actor "
                   "forward and the sample as PyTorch ops, graph = 10 steps per HIP-graph replay; actor_graph = the same "
-                  "with the library's own actor kernel (uavtrack_actor_actions); actor_fused = uavtrack_run_actor, "
+                  "with the library's own actor kernel (uavtrack_actor_actions); actor_chunks = BatchedRollout(fuse_chunks=True): "
+                  "every 10 steps as ONE uavtrack_run_actor launch (same bits as the 20 kernels of the graph form); actor_fused = uavtrack_run_actor, "
                   "actor and step of a whole 200-step episode in one launch (the rollout of train.operate_epoch); "
                   "greedy_graph / greedy_fused = the same two forms with the reference's C-METHOD baseline policy "
                   "(uav.py:324-369) instead of the actor")

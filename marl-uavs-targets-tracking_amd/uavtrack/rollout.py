@@ -47,9 +47,16 @@ class BatchedRollout:
     `sync_actor()` after every learner update to upload the new weights."""
 
     def __init__(self, env: BatchedUavEnv, policy, select: Callable[[torch.Tensor], torch.Tensor] = sample_actions,
-                 steps_per_graph: int = 8, use_graph: bool = True, seed: int = 0, device_actor: bool = False):
+                 steps_per_graph: int = 8, use_graph: bool = True, seed: int = 0, device_actor: bool = False,
+                 fuse_chunks: bool = False):
+        """fuse_chunks (library policies only: device_actor or "greedy"): run() issues every `steps_per_graph` steps as
+        ONE launch with the policy inside the step kernel (uavtrack_run_actor / uavtrack_run_greedy with T = k -- the
+        same bits as k x (policy kernel, step), see tests) instead of replaying a graph of 2 k kernels: a kernel boundary
+        costs this path more than the step itself (a T = 1 launch is ~7 us of GPU time for a 2.6 us step)."""
         self.env, self.policy, self.select, self.seed = env, policy, select, seed
         self.device_actor = device_actor
+        self.fuse_chunks = bool(fuse_chunks) and (device_actor or isinstance(policy, str))
+        self._chunk_out: Optional[Dict[str, torch.Tensor]] = None
         if device_actor:
             env.set_actor(policy)
         self.k = max(1, int(steps_per_graph))
@@ -104,6 +111,13 @@ class BatchedRollout:
     def run(self, steps: int) -> Dict[str, torch.Tensor]:
         """Advance `steps` closed-loop steps; returns the episode accumulators so far."""
         done = 0
+        if self.fuse_chunks:
+            while steps - done >= self.k:
+                self._fused_chunk(self.k)
+                done += self.k
+            if steps - done:
+                self._fused_chunk(steps - done)
+            return {"ep_sums": self.ep, "obs": self.obs, "reward": self.last_reward}
         if self.use_graph and steps >= self.k:
             if self._graph is None:
                 self._capture()
@@ -113,6 +127,19 @@ class BatchedRollout:
         for _ in range(steps - done):
             self._one_step()
         return {"ep_sums": self.ep, "obs": self.obs, "reward": self.last_reward}
+
+    def _fused_chunk(self, k: int):
+        """k closed-loop steps of the library policy + environment in one launch; state of the driver as after k _one_step()."""
+        if self.device_actor:
+            out = self._chunk_out if self._chunk_out is not None and self._chunk_out["reward"].shape[0] == k else None
+            res = self.env.run_actor(k, self.obs, seed=self.seed, want_terms=True, out=out)
+            if out is None and k == self.k:
+                self._chunk_out = res
+        else:
+            res = self.env.run_greedy(k, seed=self.seed, want_actions=False)
+        self.obs.copy_(res["obs"][-1])
+        self.last_reward.copy_(res["reward"][-1])
+        self.ep += res["ep_sums"]
 
     def sync_actor(self):
         """Upload the policy's current parameters to the library (device_actor mode; after a learner update)."""

@@ -1107,15 +1107,33 @@ def test_closed_loop_device_actor_graph_eager_fused_agree(uavtrack):
     actor.load_state_dict(sd)
     cfg = uavtrack.EnvConfig(n_envs=96, n_uav=20, m_targets=10)
     res = {}
-    for name in ("eager", "graph", "fused"):
+    for name in ("eager", "graph", "fused", "chunks"):
         env = uavtrack.BatchedUavEnv(cfg)
-        ro = uavtrack.BatchedRollout(env, actor, steps_per_graph=5, use_graph=(name == "graph"), seed=8, device_actor=True)
+        ro = uavtrack.BatchedRollout(env, actor, steps_per_graph=5, use_graph=(name == "graph"), seed=8, device_actor=True,
+                                     fuse_chunks=(name == "chunks"))
         ro.reset(seed=3)
         out = ro.run_fused(17) if name == "fused" else ro.run(17)
-        res[name] = (out["obs"][-1].clone() if name == "fused" else out["obs"].clone(), out["ep_sums"].clone())
+        res[name] = (out["obs"][-1].clone() if name == "fused" else out["obs"].clone(), out["ep_sums"].clone(),
+                     env.get_state())
     assert torch.equal(res["eager"][0], res["graph"][0]) and torch.equal(res["eager"][1], res["graph"][1])
     assert torch.equal(res["eager"][0], res["fused"][0])
     np.testing.assert_allclose(res["fused"][1].cpu().numpy(), res["eager"][1].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    # run() in fused chunks (3 launches of 5 steps + one of 2): the same trajectory, bit for bit
+    assert torch.equal(res["eager"][0], res["chunks"][0])
+    for k, v in res["eager"][2].items():
+        assert torch.equal(v, res["chunks"][2][k]), k
+    np.testing.assert_allclose(res["chunks"][1].cpu().numpy(), res["eager"][1].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    # ... and with the C-METHOD baseline policy
+    gr = {}
+    for name in ("eager", "chunks"):
+        env = uavtrack.BatchedUavEnv(cfg)
+        ro = uavtrack.BatchedRollout(env, "greedy", steps_per_graph=4, use_graph=False, seed=5, fuse_chunks=(name == "chunks"))
+        ro.reset(seed=4)
+        out = ro.run(11)
+        gr[name] = (out["obs"].clone(), env.get_state())
+    assert torch.equal(gr["eager"][0], gr["chunks"][0])
+    for k, v in gr["eager"][1].items():
+        assert torch.equal(v, gr["chunks"][1][k]), k
 
 
 
