@@ -423,9 +423,9 @@ def pmi_roofline(args, roof, units_per_launch):
     scheme_env = os.environ.get("UAVTRACK_PMI_SCHEME", "")
     fp32_forced = os.environ.get("UAVTRACK_PMI_FP32", "0") not in ("", "0") or scheme_env == "fp32"
     split = 64 <= hp <= 128 and not fp32_forced
-    # f16 x 3 (pmi_score_h3_kernel) unless forced otherwise; the library itself falls back to bf16 x 6 for networks whose
+    # f16 x 3, pairs on the lanes (pmi_score_t3_kernel) unless forced otherwise; the library itself falls back to bf16 x 6 for networks whose
     # operands could leave f16's range (none of the synthetic / reference-initialised ones do)
-    scheme = "fp32" if not split else ("x6" if scheme_env == "x6" else "h3")
+    scheme = "fp32" if not split else (scheme_env if scheme_env in ("x6", "h3") else "t3")
     call_s = sum(roof["ms"]) * 1e-3
     sc = roof["kernels"].get("scorer", {"ms": 0.0, "launches": 0})
     scorer_s = sc["ms"] * 1e-3 if sc["launches"] else call_s
@@ -448,8 +448,9 @@ def pmi_roofline(args, roof, units_per_launch):
         # THREE MFMAs per fp32 product, pmi_score_h3_kernel) or bf16 (three parts: SIX, pmi_score_x6_kernel) terms.  The
         # roof that bounds it is the 16-bit matrix rate (f16 and bf16 MFMAs take the same cycles); `achieved` counts the
         # flops the matrix cores really execute, not the fp32-equivalent work.
-        nprod = 3.0 if scheme == "h3" else 6.0
-        executed = pairs * nprod * 2.0 * 3 * hp * hp
+        nprod = 6.0 if scheme == "x6" else 3.0
+        # (the transposed kernel t3 also runs the 12 -> 3H branch layers on the matrix cores: 16 padded inputs x 3H units)
+        executed = pairs * nprod * 2.0 * (3 * hp * hp + (16 * 3 * hp if scheme == "t3" else 0))
         return {
             "bound": "mfma", "kernel": f"pmi_score_{scheme}_kernel<{hp}>", "achieved": executed / scorer_s / 1e12,
             "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": executed / scorer_s / 1e12 / BF16_MFMA_PEAK_TFLOPS,

@@ -414,11 +414,12 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
     const size_t HP = (size_t)hp, n_dev = 12 * HP + 3 * HP + 3 * HP * HP + HP + HP + 1;
     const size_t x6_off = (n_dev + 3) & ~(size_t)3, x6_len = pmi_x6_floats(hp);     // the bf16 planes, 16-B aligned
     const size_t h3_off = x6_off + x6_len, h3_len = pmi_h3_floats(hp);               // the f16 planes behind them
+    const size_t l1_off = h3_off + h3_len, l1_len = pmi_l1_floats(hp);               // ... and the branch layers' f16 planes
     if (env->pmi.n_floats != n_dev) {
         HIP_TRY(hipStreamSynchronize(st));
         if (env->pmi.blob) (void)hipFree(env->pmi.blob);
         env->pmi = PmiWeights();
-        HIP_TRY(dmalloc(&env->pmi.blob, h3_off + h3_len));
+        HIP_TRY(dmalloc(&env->pmi.blob, l1_off + l1_len));
     }
     bool h3_ok = h3_len != 0;
     {   // fc1 goes up in the scorer's register order; the copy has completed before `packed` dies
@@ -471,16 +472,22 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
                 k0 += fan[br];
             }
             for (size_t k = 0; k < 3 * HP * HP; ++k) w_max = std::fmax(w_max, std::fabs(pw[k]));
+            for (size_t k = 0; k < 15 * HP; ++k) w_max = std::fmax(w_max, std::fabs(padded[k]));      // the branch layers (MFMA operands of pmi_score_t3_kernel)
+            w_max = std::fmax(w_max, pos * pos);                                                         // ... and their inputs
             h3_ok = std::isfinite(act_max) && act_max < 32000.0 && w_max < 32000.0;
         }
+        std::vector<uint16_t> planes1(l1_len * 2);
         if (h3_ok) {
             pack_pmi_h3(padded.data(), planes3.data(), hp);
             HIP_TRY(hipMemcpyAsync(env->pmi.blob + h3_off, planes3.data(), h3_len * 4, hipMemcpyHostToDevice, st));
+            pack_pmi_l1(padded.data(), planes1.data(), hp);
+            HIP_TRY(hipMemcpyAsync(env->pmi.blob + l1_off, planes1.data(), l1_len * 4, hipMemcpyHostToDevice, st));
         }
         HIP_TRY(hipStreamSynchronize(st));
     }
     env->pmi.x6 = x6_len ? env->pmi.blob + x6_off : nullptr;
     env->pmi.h3 = h3_ok ? env->pmi.blob + h3_off : nullptr;
+    env->pmi.l1 = h3_ok ? env->pmi.blob + l1_off : nullptr;
     env->pmi.hidden = hp;
     env->pmi.n_floats = n_dev;
     if (ensure_pmi_scratch(env, 1, st)) return 1;

@@ -113,6 +113,7 @@ struct PmiWeights {
     const void *x6 = nullptr; // -> into blob: fc1 as three bf16 planes in MFMA operand order (pack_pmi_x6), or null
     const void *h3 = nullptr; // -> into blob: fc1 as two f16 planes (hi, lo * 2^11) in MFMA operand order (pack_pmi_h3), or null
                               //    (also null when the network's weights / activation bounds do not fit f16's range)
+    const void *l1 = nullptr; // -> into blob: the branch layers as f16 planes in MFMA A-operand order (pack_pmi_l1), with h3
     int32_t hidden = 0;
     size_t n_floats = 0;
 };
@@ -180,6 +181,8 @@ inline size_t pmi_x6_floats(int hp) { return hp >= kPmiX6MinHidden && hp <= kPmi
 void pack_pmi_x6(const float *abi_blob, uint16_t *planes, int hidden);
 inline size_t pmi_h3_floats(int hp) { return hp >= kPmiX6MinHidden && hp <= kPmiX6MaxHidden ? (size_t)3 * hp * hp : 0; }   // 2 planes x 2 B
 void pack_pmi_h3(const float *abi_blob, uint16_t *planes, int hidden);
+inline size_t pmi_l1_floats(int hp) { return pmi_h3_floats(hp) ? (size_t)(hp / 32) * 3 * 2 * 64 * 8 / 2 : 0; }   // [w][branch][plane][lane][8] x 2 B
+void pack_pmi_l1(const float *abi_blob, uint16_t *planes, int hidden);
 // (pairs / scores / n_uav default to the handle's MAAC-R scratch and swarm size; uavtrack_pmi_inference passes its own)
 hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream_t stream, const uint2 *pairs = nullptr,
                             float *scores = nullptr, int n_uav = 0);

@@ -60,6 +60,7 @@ struct PmiParams {
     const float *blob;       // folded weights, layout of uavtrack_set_pmi_weights
     const void *x6;          // fc1 as three bf16 planes in MFMA B-operand order (pack_pmi_x6)
     const void *h3;          // fc1 as two f16 planes (hi, lo * 2^11) in MFMA B-operand order (pack_pmi_h3), or null
+    const void *l1;          // the three branch layers as f16 planes in MFMA A-operand order (pack_pmi_l1), with h3
     const float *obs;        // [S][B][N][12] local states of the chunk's steps
     const uint2 *pairs;      // {flat [step][b][i] index of i within the chunk, j}
     const unsigned *pair_count;
@@ -873,6 +874,294 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_h3_kernel(const PmiParams 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// pmi_score_t3_kernel<H>: the f16 x 3 scorer with the PAIRS ON THE LANES (every product transposed).  In the two kernels
+// above a wavefront's VALU work beside the MFMAs -- branch layers, ReLU, operand split, DPP reductions -- outweighs the
+// matrix pipe once the products are three per fp32 product.  Transposed, most of it goes away:
+//   * layer 1 (12 -> 3H, PMINet.py:50-55) runs on the matrix cores too: H1^T[32 units x 32 pairs] = Wb^T[32 x 16] .
+//     X^T[16 x 32], the bias riding as input 12 (x_12 = 1) -- three MFMAs per block of 32 units, three blocks (one per
+//     branch) per wavefront and tile, instead of 24 scalar FMAs per pair and thread;
+//   * a 32x32 accumulator tile holds, per lane, 16 rows of ONE column: with the pairs as columns a lane owns 16 hidden
+//     units of its pair in groups of four adjacent ones, so ReLU and the f16 split stay in the lane and leave as two
+//     ds_write_b64 per group into the activation planes (row = pair, unit index contiguous) -- the layout layer 2 reads;
+//   * layer 2 (3H -> H) is the same MFMA with the operands swapped (weights as A: the very fragments pack_pmi_h3 builds;
+//     activations as B: the very LDS addresses the A fragments came from), which leaves H2^T in the accumulators: fc2
+//     (PMINet.py:61) is then 16 FMAs down the lane's registers, no cross-lane reduction at all -- the two halves of a
+//     wavefront and the column blocks are added by the thread that stores the score, as before.
+// Accuracy and range: pmi_score_h3_kernel's (same split, same two accumulators per tile; layer 1 now also rounds through
+// an fp32 MFMA accumulation of 13 terms instead of an fmaf chain -- both within 2^-22 relative of the exact sum).
+template <int H>
+__global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams q)
+{
+    constexpr int K = 3 * H;             // fc1 input width
+    constexpr int KS = K / 16;           // MFMA k-steps of layer 2 (32x32x16)
+    constexpr int PITCH = K * 2 + 16;    // bytes per activation row of one plane
+    constexpr int PLANE = 32 * PITCH;    // bytes per plane of a tile
+    constexpr int NP = 2;                // planes: hi, lo * 2^11
+    constexpr int NW = H / 32;           // wavefronts = column blocks of layer 2 = unit blocks per branch of layer 1
+    constexpr int XROW = 16;             // floats per row of the x staging buffer: x_0..11, 1, 0, 0, 0
+
+    __shared__ float4 lds4[(2 * NP * PLANE + (2 * 32 * XROW + 2 * NW * 64) * 4) / 16 + 2];
+    static_assert(H != 64 || 2 * sizeof(lds4) <= 160 * 1024, "two H = 64 workgroups no longer share a CU");
+    unsigned char *aplanes = reinterpret_cast<unsigned char *>(lds4);               // [2 tiles][2 planes][32 pairs][PITCH]
+    float *xs = reinterpret_cast<float *>(aplanes + 2 * NP * PLANE);               // [2 tiles][32 pairs][XROW]
+    float *part = xs + 2 * 32 * XROW;                                              // [2 tiles][NW][64 lanes]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int pr32 = lane & 31;          // the pair (column) this lane holds in every accumulator tile
+    const int kh = lane >> 5;
+
+    // ---- stationary operands
+    const float *b1 = q.blob + 15 * H + (size_t)K * H;
+    const float *w2 = b1 + H;
+    const float b2 = w2[H];
+    u32x4 Ah[KS], Al[KS];                 // layer 2: W1^T fragments (pack_pmi_h3's B fragments serve as A of the transposed product)
+    {
+        const u32x4 *bp = reinterpret_cast<const u32x4 *>(q.h3) + (size_t)w * NP * KS * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            Ah[s] = bp[(0 * KS + s) * 64];
+            Al[s] = bp[(1 * KS + s) * 64];
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { asm volatile("" : "+a"(Ah[s])); asm volatile("" : "+a"(Al[s])); }
+    }
+    u32x4 L1h[3], L1l[3];                 // layer 1: this wavefront's block of 32 units of each branch (pack_pmi_l1)
+    {
+        const u32x4 *lp = reinterpret_cast<const u32x4 *>(q.l1) + (size_t)w * 3 * NP * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { L1h[j] = lp[(j * NP + 0) * 64]; L1l[j] = lp[(j * NP + 1) * 64]; }
+    }
+    // accumulator row r of a lane is column (unit) m(r) = (r & 3) + 8 (r >> 2) + 4 kh of the wavefront's 32
+    f32x16 biasv, w2r;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        biasv[r] = b1[m];
+        w2r[r] = w2[m];
+    }
+
+    // where this lane's 4-unit groups of layer-1 block j land in an activation row: byte (j H + 32 w + 4 kh + 8 g) * 2
+    const int obase = pr32 * PITCH + 2 * (32 * w + 4 * kh);
+    const int bfrag0 = pr32 * PITCH + kh * 16;           // B fragments of layer 2: row = pair, 8 consecutive k per half-wave
+    const int xoff = pr32 * XROW + kh * 8;               // this lane's eight inputs of the layer-1 B operand
+
+    const unsigned npairs = *q.pair_count;
+    const unsigned ntiles = (npairs + 31) >> 5;
+    const unsigned G = gridDim.x;
+    if (blockIdx.x == 0 && tid == 0) *q.pair_total += npairs;      // accounting only (one writer)
+
+    auto load_rec = [&](unsigned tile, uint2 &pr, bool &ok) {
+        const unsigned pi = tile * 32 + lane;                  // (lanes 0..31 of the wavefront on duty)
+        ok = lane < 32 && tile < ntiles && pi < npairs;
+        pr = make_uint2(0, 0);
+        if (ok) pr = q.pairs[pi];
+    };
+    auto load_obs = [&](uint2 pr, bool ok, float4 (&a)[3], float4 (&b)[3]) {
+        a[0] = a[1] = a[2] = b[0] = b[1] = b[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+            const unsigned gi = pr.x, gj = (pr.x / q.N) * q.N + pr.y;
+            const float4 *oi = reinterpret_cast<const float4 *>(q.obs + (size_t)gi * 12);
+            const float4 *oj = reinterpret_cast<const float4 *>(q.obs + (size_t)gj * 12);
+#pragma unroll
+            for (int v = 0; v < 3; ++v) { a[v] = oi[v]; b[v] = oj[v]; }
+        }
+    };
+    auto stash = [&](int buf, const float4 (&a)[3], const float4 (&b)[3]) {       // x = la_i * la_j (uav.py:281), then 1, 0, 0, 0
+        if (lane < 32) {
+            float4 *dst = reinterpret_cast<float4 *>(xs + buf * 32 * XROW + lane * XROW);
+#pragma unroll
+            for (int v = 0; v < 3; ++v) dst[v] = make_float4(a[v].x * b[v].x, a[v].y * b[v].y, a[v].z * b[v].z, a[v].w * b[v].w);
+            dst[3] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+        }
+    };
+
+    // ---- the producer of one tile's activation planes, as a list of items of one or two instructions each that the main
+    //      loop deals out behind its MFMAs: X (operand of layer 1 from the staged inputs), M (its nine MFMAs), P (ReLU,
+    //      split and stores of a block), in the order X M0 M1 P0 M2 P1 P2 -- a block's MFMAs are issued a block ahead of
+    //      the items that read their result, and at most two blocks' accumulators are live.
+    struct Prod {
+        float4 xa, xb;                    // the lane's eight inputs
+        unsigned xh[4], xl[4];            // ... as f16 pairs: hi plane, lo plane (B operand of layer 1)
+        f32x16 ah[2], al[2];              // accumulators of two blocks in flight (block j uses slot j & 1)
+        f2 t[2];                          // remainder of the group in flight
+        unsigned pk[2];
+    };
+    constexpr int NX = 2 + 4 * 5;                         // two loads; per input pair: pack, convert back, subtract, scale, pack
+    constexpr int NPB = 16 + 4 * 10;                      // per block: 16 x (combine, ReLU); per group of four units ten items
+    constexpr int I_M0 = NX, I_M1 = I_M0 + 3, I_P0 = I_M1 + 3, I_M2 = I_P0 + NPB, I_P1 = I_M2 + 3, I_P2 = I_P1 + NPB;
+    constexpr int NITEM = I_P2 + NPB;
+    auto post_item = [&](Prod &P, auto jc, auto ic, int abuf) {
+        constexpr int j = decltype(jc)::value, i = decltype(ic)::value, sl = j & 1;
+        if constexpr (i < 16) {          // order combine + ReLU (bit-pattern max: one instruction on an MFMA result)
+            P.ah[sl][i] = __int_as_float(max(__float_as_int(fmaf(P.al[sl][i], kH3LoInv, P.ah[sl][i])), 0));
+        } else {
+            constexpr int g = (i - 16) / 10, st = (i - 16) % 10;
+            unsigned char *dst = aplanes + abuf * NP * PLANE + obase + 2 * j * H + 16 * g;
+            const f2 v0 = f2{P.ah[sl][4 * g + 0], P.ah[sl][4 * g + 1]}, v1 = f2{P.ah[sl][4 * g + 2], P.ah[sl][4 * g + 3]};
+            if constexpr (st == 0) { P.pk[0] = pk_f16(v0); P.pk[1] = pk_f16(v1); }
+            else if constexpr (st == 1) *reinterpret_cast<uint2 *>(dst) = make_uint2(P.pk[0], P.pk[1]);
+            else if constexpr (st == 2) P.t[0] = unpk_f16(P.pk[0]);
+            else if constexpr (st == 3) P.t[1] = unpk_f16(P.pk[1]);
+            else if constexpr (st == 4) P.t[0] = sub2(v0, P.t[0]);
+            else if constexpr (st == 5) P.t[1] = sub2(v1, P.t[1]);
+            else if constexpr (st == 6) P.t[0] = scale2(P.t[0], kH3LoScale);
+            else if constexpr (st == 7) P.t[1] = scale2(P.t[1], kH3LoScale);
+            else if constexpr (st == 8) { P.pk[0] = pk_f16(P.t[0]); P.pk[1] = pk_f16(P.t[1]); }
+            else *reinterpret_cast<uint2 *>(dst + PLANE) = make_uint2(P.pk[0], P.pk[1]);
+        }
+    };
+    auto mfma_item = [&](Prod &P, auto jc, auto tc) {
+        constexpr int j = decltype(jc)::value, t = decltype(tc)::value, sl = j & 1;
+        const u32x4 xh = {P.xh[0], P.xh[1], P.xh[2], P.xh[3]}, xl = {P.xl[0], P.xl[1], P.xl[2], P.xl[3]};
+        f32x16 zero;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
+        if constexpr (t == 0) P.al[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(L1l[j]), as_f16x8(xh), zero, 0, 0, 0);
+        else if constexpr (t == 1) P.al[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(L1h[j]), as_f16x8(xl), P.al[sl], 0, 0, 0);
+        else P.ah[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(L1h[j]), as_f16x8(xh), zero, 0, 0, 0);
+    };
+    auto item = [&](Prod &P, auto ic, int xbuf, int abuf) {
+        constexpr int I = decltype(ic)::value;
+        if constexpr (I == 0) P.xa = *reinterpret_cast<const float4 *>(xs + xbuf * 32 * XROW + xoff);
+        else if constexpr (I == 1) P.xb = *reinterpret_cast<const float4 *>(xs + xbuf * 32 * XROW + xoff + 4);
+        else if constexpr (I < NX) {
+            constexpr int pi = (I - 2) / 5, st = (I - 2) % 5;      // input pair pi = inputs 2 pi, 2 pi + 1 of this lane's eight
+            const float4 &f = pi < 2 ? P.xa : P.xb;
+            const f2 v = (pi & 1) ? f2{f.z, f.w} : f2{f.x, f.y};
+            if constexpr (st == 0) P.xh[pi] = pk_f16(v);
+            else if constexpr (st == 1) P.t[0] = unpk_f16(P.xh[pi]);
+            else if constexpr (st == 2) P.t[0] = sub2(v, P.t[0]);
+            else if constexpr (st == 3) P.t[0] = scale2(P.t[0], kH3LoScale);
+            else P.xl[pi] = pk_f16(P.t[0]);
+        }
+        else if constexpr (I < I_M1) mfma_item(P, std::integral_constant<int, 0>{}, std::integral_constant<int, I - I_M0>{});
+        else if constexpr (I < I_P0) mfma_item(P, std::integral_constant<int, 1>{}, std::integral_constant<int, I - I_M1>{});
+        else if constexpr (I < I_M2) post_item(P, std::integral_constant<int, 0>{}, std::integral_constant<int, I - I_P0>{}, abuf);
+        else if constexpr (I < I_P1) mfma_item(P, std::integral_constant<int, 2>{}, std::integral_constant<int, I - I_M2>{});
+        else if constexpr (I < I_P2) post_item(P, std::integral_constant<int, 1>{}, std::integral_constant<int, I - I_P1>{}, abuf);
+        else post_item(P, std::integral_constant<int, 2>{}, std::integral_constant<int, I - I_P2>{}, abuf);
+    };
+
+    // ---- prologue: the first tile's activation planes; the second tile's inputs in xs[1]; the third's observations
+    //      and the fourth's pair record in flight
+    // The tile inputs (pair record -> the two observations -> x) are two dependent trips to memory, and the observation
+    // rows are a random gather from hundreds of megabytes: ~2 us under load, a whole tile time of this kernel.  The duty
+    // therefore rotates over the wavefronts -- the inputs of iteration j are staged by wavefront j mod NW, which requested
+    // the observations NW iterations and the record 2 NW iterations ahead: every request has NW tile times to arrive.
+    uint2 rec_n;
+    bool rec_ok;
+    float4 oa[3], ob[3];
+    auto tile_of = [&](unsigned j) { return blockIdx.x + j * G; };
+    {
+        if (w == 0) {                                      // iterations 0 and 1: staged here, synchronously
+            load_rec(tile_of(0), rec_n, rec_ok);
+            load_obs(rec_n, rec_ok, oa, ob);
+            stash(0, oa, ob);
+            load_rec(tile_of(1), rec_n, rec_ok);
+            load_obs(rec_n, rec_ok, oa, ob);
+            stash(1, oa, ob);
+        }
+        const unsigned j0 = 2u + (unsigned)((w + NW - 2 % NW) % NW);     // this wavefront's first duty: the iteration j0 >= 2 with j0 mod NW == w
+        load_rec(tile_of(j0), rec_n, rec_ok);
+        load_obs(rec_n, rec_ok, oa, ob);
+        load_rec(tile_of(j0 + NW), rec_n, rec_ok);
+        __syncthreads();
+        Prod P0;
+        static_for<NITEM>([&](auto ic) { item(P0, ic, 0, 0); });
+        __syncthreads();
+    }
+
+    // fc2 (PMINet.py:60-61) of a finished tile: ReLU(H2) . w2 down the lane's 16 rows; 17 items
+    auto epi_item = [&](const f32x16 &ah, const f32x16 &al, float &sum, auto ec, float *pc) {
+        constexpr int e = decltype(ec)::value;
+        if constexpr (e < 16) {
+            const float v = __int_as_float(max(__float_as_int(fmaf(al[e], kH3LoInv, ah[e])), 0));
+            sum = e == 0 ? v * w2r[0] : fmaf(v, w2r[e], sum);
+        } else {
+            pc[lane] = sum;
+        }
+    };
+    const int ft = tid - (NW - 1) * 64;
+    auto final_sum = [&](unsigned tile, const float *pc) {      // over the two half-wavefronts of every column block, in order
+        if (ft >= 0 && ft < 32 && tile * 32 + ft < npairs) {
+            float sc = b2;
+#pragma unroll
+            for (int ww = 0; ww < 2 * NW; ++ww) sc += pc[ww * 32 + ft];
+            q.scores[tile * 32 + ft] = sc;
+        }
+    };
+
+    int cur = 0;
+    unsigned it = 0;
+    bool have_prev = false;
+    f32x16 accph, accpl;                     // the previous tile's accumulators: their epilogue runs under this tile's MFMAs
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accph[r] = 0.0f; accpl[r] = 0.0f; }
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += G) {
+        f32x16 acch = biasv, accl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accl[r] = 0.0f;
+        const unsigned char *bfrag = aplanes + cur * NP * PLANE + bfrag0;
+        auto load_b = [&](int s, u32x4 &h, u32x4 &l) {
+            h = *reinterpret_cast<const u32x4 *>(bfrag + 0 * PLANE + s * 32);
+            l = *reinterpret_cast<const u32x4 *>(bfrag + 1 * PLANE + s * 32);
+        };
+        Prod P;
+        float esum = 0.0f;
+        float *pcp = part + (cur ^ 1) * NW * 64 + w * 64;         // the previous tile's partial scores of this wavefront
+        u32x4 fh, fl, gh, gl;                 // this k-step's fragments, the next one's
+        load_b(0, fh, fl);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<KS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            static_for<3>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int slot = 3 * s + t, nslot = 3 * KS;
+                constexpr int lo = slot * NITEM / nslot, hi = (slot + 1) * NITEM / nslot;
+                // H2^T += W1^T H1^T, small terms first: lo += Wl Hh, lo += Wh Hl, hi += Wh Hh
+                const f16x8 a = as_f16x8(t == 0 ? Al[s] : Ah[s]);
+                const f16x8 bq = as_f16x8(t == 1 ? fl : fh);
+                if constexpr (t == 2) acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, acch, 0, 0, 0);
+                else accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, accl, 0, 0, 0);
+                if constexpr (t == 0 && s + 1 < KS) load_b(s + 1, gh, gl);
+                static_for<NITEM>([&](auto ic) {
+                    if constexpr (decltype(ic)::value >= lo && decltype(ic)::value < hi) item(P, ic, cur ^ 1, cur ^ 1);
+                });
+                constexpr int elo = slot * 17 / nslot, ehi = (slot + 1) * 17 / nslot;
+                static_for<17>([&](auto ec) {
+                    if constexpr (decltype(ec)::value >= elo && decltype(ec)::value < ehi) epi_item(accph, accpl, esum, ec, pcp);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            fh = gh; fl = gl;
+        });
+
+        // xs[cur] fed the producer during the previous iteration: free for iteration it + 2
+        if ((it + 2) % NW == (unsigned)w) {
+            stash(cur, oa, ob);                               // x of iteration it + 2 (observations requested NW iterations ago)
+            load_obs(rec_n, rec_ok, oa, ob);                  // it + 2 + NW (record requested NW iterations ago)
+            load_rec(tile_of(it + 2 + 2 * NW), rec_n, rec_ok);
+        }
+        ++it;
+        UAVTRACK_LDS_BARRIER();
+        if (have_prev) final_sum(tile - G, part + (cur ^ 1) * NW * 64);
+        accph = acch; accpl = accl;
+        have_prev = true;
+        cur ^= 1;
+    }
+    if (have_prev) {                         // the last tile's epilogue has nothing left to hide behind
+        float esum = 0.0f;
+        float *pcp = part + (cur ^ 1) * NW * 64 + w * 64;
+        static_for<17>([&](auto ec) { epi_item(accph, accpl, esum, ec, pcp); });
+        __syncthreads();
+        const unsigned last = blockIdx.x + ((ntiles - 1 - blockIdx.x) / G) * G;
+        final_sum(last, part + (cur ^ 1) * NW * 64);
+    }
+}
+
 struct MixParams {
     const uint32_t *nbrec;       // [S][B][N][W + 2] neighbour records of the chunk's S steps
     const float *scores;         // one per pair
@@ -1077,6 +1366,33 @@ void pack_pmi_h3(const float *abi_blob, uint16_t *planes, int H)
                 }
 }
 
+// The branch layers (PMINet.py:50-55, BatchNorm folded) for pmi_score_t3_kernel: per wavefront w and branch j the block of
+// 32 units [32 w, 32 w + 32) as the A operand of v_mfma_f32_32x32x16_f16 over the 16 "inputs" x_0..x_11, 1, 0, 0, 0 --
+// row = unit, k = input: the branch's own inputs carry its weights, input 12 its bias, the rest zeros.  Two planes
+// (f16(v), f16((v - plane 0) * 2^11)); lane l holds k = 8 (l >> 5) .. + 7 of row l & 31.
+void pack_pmi_l1(const float *abi_blob, uint16_t *planes, int H)
+{
+    const int NW = H / 32;
+    const int k0[3] = {0, 5, 9}, fan[3] = {5, 4, 3};
+    const size_t woff[3] = {0, (size_t)6 * H, (size_t)11 * H};
+    for (int w = 0; w < NW; ++w)
+        for (int j = 0; j < 3; ++j)
+            for (int l = 0; l < 64; ++l)
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int unit = 32 * w + (l & 31), k = 8 * (l >> 5) + jj;
+                    float v = 0.0f;
+                    if (k >= k0[j] && k < k0[j] + fan[j]) v = abi_blob[woff[j] + (size_t)(k - k0[j]) * H + unit];
+                    else if (k == 12) v = abi_blob[woff[j] + (size_t)fan[j] * H + unit];
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
+                    uint16_t bh, bl;
+                    memcpy(&bh, &hi, 2);
+                    memcpy(&bl, &lo, 2);
+                    planes[((((size_t)w * 3 + j) * 2 + 0) * 64 + l) * 8 + jj] = bh;
+                    planes[((((size_t)w * 3 + j) * 2 + 1) * 64 + l) * 8 + jj] = bl;
+                }
+}
+
 hipError_t launch_pmi_inference_prep(const float *x, float *obs2, uint2 *pairs, unsigned n, hipStream_t stream)
 {
     hipLaunchKernelGGL(pmi_inference_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, stream,
@@ -1090,6 +1406,7 @@ hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream
     q.blob = env->pmi.blob;
     q.x6 = env->pmi.x6;
     q.h3 = env->pmi.h3;
+    q.l1 = env->pmi.l1;
     q.obs = obs;
     q.pairs = pairs ? pairs : env->pairs;
     q.pair_count = env->pair_count;
@@ -1109,8 +1426,23 @@ hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream
     // uavtrack_set_pmi_weights), else bf16 x 6, else the fp32-MFMA kernel
     static const int scheme = [] {
         const char *s = getenv("UAVTRACK_PMI_SCHEME");
-        return !s ? 0 : !strcmp(s, "h3") ? 1 : !strcmp(s, "x6") ? 2 : !strcmp(s, "fp32") ? 3 : 0;
+        return !s ? 0 : !strcmp(s, "h3") ? 1 : !strcmp(s, "x6") ? 2 : !strcmp(s, "fp32") ? 3 : !strcmp(s, "t3") ? 4 : 0;
     }();
+    if (q.h3 && q.l1 && !force_fp32 && (scheme == 0 || scheme == 4)) {
+        static const int mult64t = [] {
+            const char *e = getenv("UAVTRACK_T3_GRID64");
+            const int v = e ? atoi(e) : 2;
+            return v < 1 ? 1 : (v > 4 ? 4 : v);
+        }();
+        const int gridt = (env->n_cus > 0 ? env->n_cus : 256) * (env->pmi.hidden <= 64 ? mult64t : 1);
+        switch (env->pmi.hidden) {
+#define UAVTRACK_PMI_CASE(HH) case HH: hipLaunchKernelGGL(pmi_score_t3_kernel<HH>, dim3(gridt), dim3(2 * HH), 0, stream, q); break;
+            UAVTRACK_PMI_CASE(64) UAVTRACK_PMI_CASE(96) UAVTRACK_PMI_CASE(128)
+#undef UAVTRACK_PMI_CASE
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     if (q.h3 && !force_fp32 && (scheme == 0 || scheme == 1)) {
         // H = 128 / 96: one workgroup per CU, one wavefront per SIMD.  H = 64: a workgroup is two wavefronts and 52 KB of LDS
         static const int mult64h = [] {

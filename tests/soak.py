@@ -16,6 +16,8 @@ def run(B, N, M, coop, box, steps, seed, dim=2):
     orc = OracleEnv(OracleConfig(**kw), n_threads=16)
     rng = np.random.RandomState(seed)
     worst = dict(obs=0.0, rew=0.0, terms=0.0); bad_cov = 0; skipped = 0; total = 0
+    # census of the env-steps that are set aside (fp64 margin below 1e-3 m): how many of them REALLY differ from the oracle
+    cen = dict(covered=0, obs=0, reward=0, any=0)
     na = 12 * (3 if dim == 3 else 1)
     for t in range(steps):
         st = {k: v.cpu().numpy() for k, v in env.get_state().items()}
@@ -25,17 +27,28 @@ def run(B, N, M, coop, box, steps, seed, dim=2):
         ref = orc.step(act)
         ok = ref["margin"] > 1e-3
         skipped += int((~ok).sum()); total += B
+        o = obs.cpu().numpy(); r = rew.cpu().numpy(); tm = env.info["terms"].cpu().numpy(); cv = env.info["covered"].cpu().numpy()
+        if (~ok).any():
+            ko = ~ok
+            dc = (cv != ref["covered"]) & ko
+            do = ((np.abs(o - ref["obs"]) / (1.0 + np.abs(ref["obs"]))).reshape(B, -1).max(1) > 1e-5) & ko
+            dr = (np.abs(r - ref["reward"]).max(1) > 1e-5) & ko
+            cen["covered"] += int(dc.sum()); cen["obs"] += int(do.sum()); cen["reward"] += int(dr.sum()); cen["any"] += int((dc | do | dr).sum())
         if not ok.any():
             continue
-        o = obs.cpu().numpy(); r = rew.cpu().numpy(); tm = env.info["terms"].cpu().numpy(); cv = env.info["covered"].cpu().numpy()
         # near the origin the uav.py:165 weight 1/min(d,1) makes observation entries O(10..1000): mixed abs/rel
         worst["obs"] = max(worst["obs"], float((np.abs(o - ref["obs"]) / (1.0 + np.abs(ref["obs"])))[ok].max()))
         worst["rew"] = max(worst["rew"], float(np.abs(r - ref["reward"])[ok].max()))
         worst["terms"] = max(worst["terms"], float(np.abs(tm - ref["terms"])[:, ok].max()))
         bad_cov += int((cv != ref["covered"])[ok].sum())
     print(f"B{B} N{N} M{M} coop{coop} box{box} dim{dim} steps{steps}: max|obs|={worst['obs']:.2e} max|rew|={worst['rew']:.2e} "
-          f"max|terms|={worst['terms']:.2e} covered mismatches={bad_cov} knife-edge envs skipped={skipped}/{total}", flush=True)
+          f"max|terms|={worst['terms']:.2e} covered mismatches={bad_cov} knife-edge envs skipped={skipped}/{total}; of those "
+          f"really different: covered {cen['covered']}, obs {cen['obs']}, reward {cen['reward']}, any {cen['any']}", flush=True)
+    CENSUS.append((skipped, total, cen["covered"], cen["obs"], cen["reward"], cen["any"]))
     assert worst["obs"] < 1e-5 and worst["rew"] < 1e-5 and worst["terms"] < 1e-5 and bad_cov == 0
+
+CENSUS = []
+
 
 def fuzz(n_cases, seed):
     """Random shapes / boxes / modes through the same comparison: odd and even N and M, one UAV, one target,
@@ -65,4 +78,8 @@ run(2048, 20, 10, 0.3, 300.0, 150, 3)     # tiny box: everything in range, UAVs 
 run(1024, 50, 25, 0.3, 2000.0, 60, 4)
 run(1024, 50, 25, 0.0, 2000.0, 40, 5, dim=3)
 run(2048, 7, 4, 0.3, 100.0, 300, 6)       # generic kernel, box smaller than a step: origin-weight path, outside-box UAVs
+tot = np.array(CENSUS).sum(0)
+print(f"census: {tot[1]} env-steps compared, {tot[0]} set aside on a knife edge ({100.0 * tot[0] / tot[1]:.3f} %); of those the device "
+      f"really differs from the fp64 oracle in: covered count {tot[2]}, observation {tot[3]}, reward {tot[4]}, any of them {tot[5]} "
+      f"({100.0 * tot[5] / max(tot[1], 1):.4f} % of all env-steps)")
 print(f"soak ok in {time.time()-t0:.0f} s")

@@ -1003,7 +1003,7 @@ def test_bench_contract_line(uavtrack):
         r2 = c["roofline"]
         assert r2["launches_timed"] >= 10 and r2["launches_untimed_before"] >= 3 and 0.0 < r2["frac"] < 1.0
         if key.startswith("configs[2]"):
-            assert r2["bound"] == "mfma" and r2["unit"] == "TFLOP/s" and r2["peak"] == 2500.0 and "pmi_score_h3_kernel" in r2["kernel"]
+            assert r2["bound"] == "mfma" and r2["unit"] == "TFLOP/s" and r2["peak"] == 2500.0 and "pmi_score_t3_kernel" in r2["kernel"]
             assert 0.1 < r2["pairs_per_agent_step"] < 1.0 and r2["scorer_ms_per_launch"] < r2["avg_launch_ms"]
             assert r2["fp32_equivalent_over_fp32_mfma_peak"] > 1.0          # past what the fp32 matrix pipe could do at all
             assert c["agent_steps_per_s"] > (6.0e9 if "H64" in key else 4.0e9)

@@ -9,7 +9,7 @@ OUT=$ROOT/build_variants; mkdir -p $OUT/obj_$NAME
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -ffp-contract=off -I$ROOT/include -I$SRC -Wno-unused-function -Wno-pass-failed"
 for f in api reset_kernel pmi_kernel policy_kernel; do
   if [ -z "$ALLFLAGS" ] && [ -f $SRC/build/$f.o ] && [ -z "$REBUILD_ALL" ]; then cp $SRC/build/$f.o $OUT/obj_$NAME/$f.o
-  else EXTRA=""; [ $f = pmi_kernel ] && EXTRA="-fno-slp-vectorize $PMIFLAGS"; [ $f = policy_kernel ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1"
+  else EXTRA=""; [ $f = pmi_kernel ] && EXTRA="-fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form=1 $PMIFLAGS"; [ $f = policy_kernel ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1"
        /opt/rocm/bin/hipcc $FLAGS $ALLFLAGS $EXTRA -c $SRC/$f.hip -o $OUT/obj_$NAME/$f.o & fi
 done
 if [ -n "$SKIP_STEP" ] && [ -f $SRC/build/step_kernel.o ]; then cp $SRC/build/step_kernel.o $OUT/obj_$NAME/step_kernel.o
