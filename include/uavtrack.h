@@ -134,7 +134,7 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
  * uav.py:281 builds, la_i * la_j) -> scores [n] (device), with the weights of uavtrack_set_pmi_weights and on the very
  * kernels that score the neighbour pairs of a MAAC-R step (bf16 x 6 or fp32 MFMA by width) -- the network alone, for
  * callers that hold pair inputs of their own and for accuracy tests of the scorer.  Stream-ordered; must not run
- * concurrently with a MAAC-R step of the same handle.  (The pairs it scores are included in uavtrack_pmi_pairs_scored.) */
+ * concurrently with a MAAC-R step of the same handle.  (Not counted by uavtrack_pmi_pairs_scored.) */
 int uavtrack_pmi_inference(uavtrack_env *env, const float *x, int64_t n, float *scores, void *stream);
 
 /* Replaces Environment.step (environment.py:120-164) for the whole batch.
@@ -241,8 +241,8 @@ int uavtrack_run_actor(uavtrack_env *env, int32_t T, uint64_t seed, int32_t mode
  * is set (checked).  tpos = NULL switches the output off (the default). */
 int uavtrack_set_target_trace(uavtrack_env *env, float *tpos, int32_t capacity_steps);
 
-/* MAAC-R accounting for reports: out[0] = neighbour pairs scored by the PMI network since
- * the weights were set (each unordered pair once per step).  Synchronises `stream`. */
+/* MAAC-R accounting for reports: out[0] = neighbour pairs the stepping entry points have handed to the PMI network
+ * since the handle was created (each unordered pair once per step).  Synchronises `stream`. */
 int uavtrack_pmi_pairs_scored(uavtrack_env *env, uint64_t *out, void *stream);
 
 /* Measurement hook (bench.py's roofline legs): with profiling on, every kernel launch of the stepping entry points is

@@ -136,10 +136,13 @@ int ensure_pmi_scratch(uavtrack_env *env, int32_t steps, hipStream_t st)
 {
     const uavtrack_config &c = env->cfg;
     const size_t BN = (size_t)c.n_envs * c.n_uav;
-    const size_t pairs_step = BN * (c.n_uav - 1) / 2 + 1;
+    // slots per step: every pair within dp at worst -- twice that, because the single-wavefront rollout variant hands out
+    // pair-list slots in blocks and what a block has left when a step does not fit goes to dummies (less than that step's
+    // pairs each time: never more than one dummy per real pair), plus a block per workgroup for the end of the launch
+    const size_t pairs_step = BN * (c.n_uav - 1) + (size_t)env->geo.groups * 64 + 1;
     const size_t rec_bytes = (size_t)nbrec_words(c.n_uav) * 4;
     const size_t per_step = pairs_step * (sizeof(uint2) + 4) + BN * rec_bytes + BN * UAVTRACK_OBS_DIM * 4 + (size_t)c.n_envs * 4;
-    size_t budget = (size_t)2048 << 20;
+    size_t budget = (size_t)8192 << 20;        // (of 288 GB: a 200-step rollout of the reference shape stays one chunk)
     if (const char *s = getenv("UAVTRACK_PMI_SCRATCH_MB")) budget = (size_t)atoll(s) << 20;
     int64_t cap = (int64_t)(budget / per_step);
     const int64_t idx_cap = (int64_t)(0xFFFFFFFFull / BN);     // pair records carry a 32-bit flat [step][b][i] index
@@ -548,7 +551,7 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
     p.tpos = env->tpos;
     p.obs = obs; p.reward = reward; p.terms = terms; p.nbrec = nullptr;
     p.covered = covered; p.done = done; p.ep_sums = ep_sums;
-    p.pairs = nullptr; p.pair_count = nullptr;
+    p.pairs = nullptr; p.pair_count = nullptr; p.pair_total = nullptr;
     p.ep_accumulate = accumulate ? 1 : 0;
     p.actions_out = pol.actions_out;
     p.env_offset = env->cfg.env_offset;
@@ -578,6 +581,7 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
     p.nbrec = env->nbrec;
     p.pairs = env->pairs;
     p.pair_count = env->pair_count;      // zero: set at allocation, re-zeroed by the mix kernel
+    p.pair_total = env->pair_total;
     bool add = accumulate;
     for (int32_t t0 = 0; t0 < T; t0 += env->pmi_steps_cap) {
         const int32_t n = (T - t0 < env->pmi_steps_cap) ? T - t0 : env->pmi_steps_cap;

@@ -68,6 +68,7 @@ struct StepParams {
     float *ep_sums;
     uint2 *pairs;            // MAAC-R: neighbour pair list {flat [t][b][i] index of i, j}, i < j
     unsigned *pair_count;
+    unsigned long long *pair_total;   // accounting: neighbour pairs emitted so far (uavtrack_pmi_pairs_scored)
     // geometry
     int32_t B, N, M, E, T, na, na_total, horizon;
     int32_t ep_accumulate;   // 1: ep_sums += (uavtrack_step_accumulate), 0: ep_sums = sums of this launch

@@ -136,15 +136,14 @@ __global__ void __launch_bounds__(H * 2, 2) pmi_score_kernel(const PmiParams q)
 
     const unsigned npairs = *q.pair_count;
     const unsigned ntiles = (npairs + 31) >> 5;
-    if (blockIdx.x == 0 && tid == 0) *q.pair_total += npairs;      // accounting only (one writer)
 
     // gather of one pair by the first 32 threads: pair record + x = la_i * la_j (uav.py:281)
     auto gather = [&](unsigned tile, uint2 &pr, float4 (&x)[3]) {
         const unsigned pi = tile * 32 + tid;
         pr = make_uint2(0, 0);
         x[0] = x[1] = x[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tid < 32 && tile < ntiles && pi < npairs) {
-            pr = q.pairs[pi];
+        if (tid < 32 && tile < ntiles && pi < npairs) pr = q.pairs[pi];
+        if (tid < 32 && tile < ntiles && pi < npairs && pr.x != 0xFFFFFFFFu) {      // (skips the dummies of the rollout kernel's slot pool)
             const unsigned gi = pr.x, gj = (pr.x / q.N) * q.N + pr.y;
             const float4 *oi = reinterpret_cast<const float4 *>(q.obs + (size_t)gi * 12);
             const float4 *oj = reinterpret_cast<const float4 *>(q.obs + (size_t)gj * 12);
@@ -370,7 +369,6 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
     const unsigned npairs = *q.pair_count;
     const unsigned ntiles = (npairs + 31) >> 5;
     const unsigned G = gridDim.x;
-    if (blockIdx.x == 0 && tid == 0) *q.pair_total += npairs;      // accounting only (one writer)
 
     // Inputs of a tile, by the first 32 threads: pair record -> the two observations -> x = la_i * la_j (uav.py:281).
     // Two dependent trips to memory, so the main loop runs them as a pipeline one tile deep each: a record is
@@ -384,7 +382,7 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
     };
     auto load_obs = [&](uint2 pr, bool ok, float4 (&a)[3], float4 (&b)[3]) {
         a[0] = a[1] = a[2] = b[0] = b[1] = b[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) {
+        if (ok && pr.x != 0xFFFFFFFFu) {     // (tested HERE, where the record is needed anyway: 0xFFFFFFFF = a dummy of the rollout kernel's slot pool)
             const unsigned gi = pr.x, gj = (pr.x / q.N) * q.N + pr.y;
             const float4 *oi = reinterpret_cast<const float4 *>(q.obs + (size_t)gi * 12);
             const float4 *oj = reinterpret_cast<const float4 *>(q.obs + (size_t)gj * 12);
@@ -692,7 +690,6 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_h3_kernel(const PmiParams 
     const unsigned npairs = *q.pair_count;
     const unsigned ntiles = (npairs + 31) >> 5;
     const unsigned G = gridDim.x;
-    if (blockIdx.x == 0 && tid == 0) *q.pair_total += npairs;      // accounting only (one writer)
 
     // input pipeline of pmi_score_x6_kernel: pair record three tiles ahead, its observations two
     auto load_rec = [&](unsigned tile, uint2 &pr, bool &ok) {
@@ -703,7 +700,7 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_h3_kernel(const PmiParams 
     };
     auto load_obs = [&](uint2 pr, bool ok, float4 (&a)[3], float4 (&b)[3]) {
         a[0] = a[1] = a[2] = b[0] = b[1] = b[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) {
+        if (ok && pr.x != 0xFFFFFFFFu) {     // (tested HERE, where the record is needed anyway: 0xFFFFFFFF = a dummy of the rollout kernel's slot pool)
             const unsigned gi = pr.x, gj = (pr.x / q.N) * q.N + pr.y;
             const float4 *oi = reinterpret_cast<const float4 *>(q.obs + (size_t)gi * 12);
             const float4 *oj = reinterpret_cast<const float4 *>(q.obs + (size_t)gj * 12);
@@ -951,7 +948,6 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
     const unsigned npairs = *q.pair_count;
     const unsigned ntiles = (npairs + 31) >> 5;
     const unsigned G = gridDim.x;
-    if (blockIdx.x == 0 && tid == 0) *q.pair_total += npairs;      // accounting only (one writer)
 
     auto load_rec = [&](unsigned tile, uint2 &pr, bool &ok) {
         const unsigned pi = tile * 32 + lane;                  // (lanes 0..31 of the wavefront on duty)
@@ -961,7 +957,7 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
     };
     auto load_obs = [&](uint2 pr, bool ok, float4 (&a)[3], float4 (&b)[3]) {
         a[0] = a[1] = a[2] = b[0] = b[1] = b[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) {
+        if (ok && pr.x != 0xFFFFFFFFu) {     // (tested HERE, where the record is needed anyway: 0xFFFFFFFF = a dummy of the rollout kernel's slot pool)
             const unsigned gi = pr.x, gj = (pr.x / q.N) * q.N + pr.y;
             const float4 *oi = reinterpret_cast<const float4 *>(q.obs + (size_t)gi * 12);
             const float4 *oj = reinterpret_cast<const float4 *>(q.obs + (size_t)gj * 12);

@@ -577,7 +577,19 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
     // list with ONE returning global atomic per step; waiting for it on the spot put a trip to L2 on every step's
     // critical path, so the reservation made at step t is consumed at step t + 1 (and behind the loop): these hold
     // what step t's lanes need to write their records and pairs then.
-    constexpr bool kPipeEmit = MODE == UAVTRACK_REWARD_PMI && N_ > 0 && N_ <= 64;
+    // Single-wavefront workgroups (LONE) take their pair-list slots from a private POOL instead: four times the workgroups
+    // would mean four times the reservations on the one counter (~10 ns each, serialised: 2.7 ms per 200 steps at 4096
+    // envs).  A wavefront reserves a block worth a few steps with one atomic, hands the slots out itself, and asks for the
+    // next block a step or two before the pool runs dry (the result is collected when it is needed); what a block has left
+    // when a step does not fit, or at the end of the launch, is filled with dummy records the scorer skips.
+    constexpr bool kPoolEmit = MODE == UAVTRACK_REWARD_PMI && N_ > 0 && N_ <= 64 && LONE;
+    constexpr bool kPipeEmit = MODE == UAVTRACK_REWARD_PMI && N_ > 0 && N_ <= 64 && !LONE;
+    constexpr unsigned kPoolBlock = 64;
+    unsigned pool_base = 0, pool_left = 0, pend_size = 0, pend_base_v = 0, real_pairs = 0;   // (wave-uniform but for pend_base_v: lane 0's)
+    bool pend = false;
+    auto pool_dummies = [&](unsigned base, unsigned n) {
+        for (unsigned k = (unsigned)tid; k < n; k += (unsigned)nthreads) p.pairs[base + k] = make_uint2(0xFFFFFFFFu, 0u);
+    };
     unsigned pe_base = 0, pe_tg = 0;        // (thread 0) the reservation in flight; flat [t][b][i] of the pending step
     int pe_mine = 0, pe_slot = 0;
     unsigned long long pe_nball = 0, pe_later = 0;
@@ -906,6 +918,72 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
         // ---- MAAC-R only: emit the neighbour pairs (i < j, d <= dp on post-move poses, uav.py:278) this
         //      workgroup owns into the global pair list the PMI scoring kernel consumes.  s_ij = s_ji
         //      (the input is la_i * la_j), so unordered pairs halve the work.
+        if (kPoolEmit) {
+            unsigned *wg_cnt = covw + 2 * E * CW;          // (a wavefront's LDS operations execute in program order)
+            if (tid == 0) wg_cnt[0] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int mine = 0, slot = 0;
+            unsigned long long nball = 0, later = 0;        // all neighbours / neighbours j > i
+            if (active) {
+                nball = nbmask & ~(1ull << i);
+                later = (i + 1 < 64) ? (nball >> (i + 1)) << (i + 1) : 0ull;
+                mine = __popcll(later);
+                if (mine) slot = (int)atomicAdd(&wg_cnt[0], (unsigned)mine);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const unsigned total = (unsigned)__builtin_amdgcn_readfirstlane((int)wg_cnt[0]);
+            unsigned first = pool_base + (unsigned)slot;
+            if (total > pool_left) {
+                // This step does not fit.  UAVs whose run of slots still fits keep the old block (they are a prefix in slot
+                // order: runs are disjoint and consecutive), the others move to the next block as one piece; what the old
+                // block has left behind the prefix -- less than one UAV's run -- goes to dummies.
+                const bool fits = (unsigned)slot + (unsigned)mine <= pool_left;
+                if (tid == 0) wg_cnt[1] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (mine && !fits) atomicAdd(&wg_cnt[1], (unsigned)mine);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const unsigned moved = (unsigned)__builtin_amdgcn_readfirstlane((int)wg_cnt[1]), cut = total - moved;
+                pool_dummies(pool_base + cut, pool_left - cut);
+                if (pend && pend_size < moved) {            // (a step far above the recent ones: the block asked for is too small as well)
+                    pool_dummies((unsigned)__builtin_amdgcn_readfirstlane((int)pend_base_v), pend_size);
+                    pend = false;
+                }
+                if (!pend) {
+                    pend_size = moved > kPoolBlock ? moved : kPoolBlock;
+                    if (tid == 0) pend_base_v = atomicAdd(p.pair_count, pend_size);
+                }
+                const unsigned nbase = (unsigned)__builtin_amdgcn_readfirstlane((int)pend_base_v);   // (waits for the reservation: as a rule made a step or more ago)
+                if (!fits) first = nbase + ((unsigned)slot - cut);
+                pool_base = nbase + moved;
+                pool_left = pend_size - moved;
+                pend = false;
+            } else {
+                pool_base += total;
+                pool_left -= total;
+            }
+            real_pairs += total;
+            if (active) {
+                uint32_t *rec = p.nbrec + (size_t)tg_off * (nbrec_mask_words(N) + 2);
+                *reinterpret_cast<uint4 *>(rec) = make_uint4((unsigned)nball, (unsigned)(nball >> 32), first, __float_as_uint(raw));
+                uint2 *dst = p.pairs + first;
+                while (later) {                      // ascending j
+                    const int j = __ffsll((long long)later) - 1;
+                    later &= later - 1;
+                    *dst++ = make_uint2(tg_off, (unsigned)j);
+                }
+            }
+            if (!pend && pool_left < 2 * total && t + 2 < p.T) {   // about to run dry: ask for the next block now, collect it later
+                pend_size = 4 * total > kPoolBlock ? 4 * total : kPoolBlock;
+                if (tid == 0) pend_base_v = atomicAdd(p.pair_count, pend_size);
+                pend = true;
+            }
+        } else
         if (kPipeEmit) {
             unsigned *wg_cnt = covw + 2 * E * CW;          // two extra words behind the coverage masks
             // (thread 0 zeroed wg_cnt[0] and published the previous step's reservation in wg_cnt[1] ahead of the
@@ -920,7 +998,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
                 if (mine) slot = (int)atomicAdd(&wg_cnt[0], (unsigned)mine);
             }
             __syncthreads();
-            if (tid == 0) pe_base = wg_cnt[0] ? atomicAdd(p.pair_count, wg_cnt[0]) : 0u;
+            if (tid == 0) { pe_base = wg_cnt[0] ? atomicAdd(p.pair_count, wg_cnt[0]) : 0u; real_pairs += wg_cnt[0]; }
             pe_mine = mine; pe_slot = slot; pe_nball = nball; pe_later = later; pe_tg = tg_off; pe_raw = raw;
         } else
         if (MODE == UAVTRACK_REWARD_PMI) {
@@ -953,7 +1031,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
                 if (mine) slot = (int)atomicAdd(&wg_cnt[0], (unsigned)mine);
             }
             __syncthreads();
-            if (tid == 0) wg_cnt[1] = wg_cnt[0] ? atomicAdd(p.pair_count, wg_cnt[0]) : 0u;
+            if (tid == 0) { wg_cnt[1] = wg_cnt[0] ? atomicAdd(p.pair_count, wg_cnt[0]) : 0u; real_pairs += wg_cnt[0]; }
             __syncthreads();
             if (active) {
                 const unsigned first = wg_cnt[1] + (unsigned)slot;
@@ -1037,6 +1115,12 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
         row += BN;
         rowb += (size_t)p.B;
     }
+    if (kPoolEmit) {                         // what the pool and an uncollected block have left
+        pool_dummies(pool_base, pool_left);
+        if (pend) pool_dummies((unsigned)__builtin_amdgcn_readfirstlane((int)pend_base_v), pend_size);
+    }
+    if (MODE == UAVTRACK_REWARD_PMI && tid == 0 && real_pairs && p.pair_total)      // accounting (uavtrack_pmi_pairs_scored)
+        atomicAdd(p.pair_total, (unsigned long long)real_pairs);
     if (kPipeEmit && p.T > 0) {              // the last step's records and pairs
         unsigned *wg_cnt = covw + 2 * E * CW;
         if (tid == 0) wg_cnt[1] = pe_base;
@@ -1140,7 +1224,7 @@ template <int N_, int M_>
 KernelFn pick_mode(int mode, bool z3, int policy, bool allout, bool extras, bool lone)
 {
     if constexpr (N_ > 0 && N_ <= 20 && M_ <= 10) {       // the shapes sweep_fast's prefetch is written for
-        if (policy == kPolicyGiven && allout && !extras && lone && !z3 && mode != UAVTRACK_REWARD_PMI)
+        if (policy == kPolicyGiven && allout && !extras && lone && !z3)
             return pick_reward<N_, M_, kPolicyGiven, true, false, true>(mode, false);
     }
     if (policy == kPolicyGreedy)
@@ -1218,7 +1302,12 @@ Geometry plan_geometry(const uavtrack_config &cfg, int n_simd)
         long waves64 = 0;
         // (MAAC-R keeps the larger groups: its pair emission costs one global atomic per workgroup-step, and
         // four times the workgroups measured 15.8 instead of 5.2 us per step at 4096 envs)
-        if (feasible(64) && cfg.reward_mode != UAVTRACK_REWARD_PMI) {
+        // (MAAC-R used to keep the larger groups -- one pair-list reservation per workgroup-step on ONE counter; the
+        // single-wavefront variant now reserves per block, see kPoolEmit -- so it follows the same rule, for the swarm
+        // sizes that variant is built for)
+        int spec_shape = 0;
+        pick_kernel(N, cfg.m_targets, cfg.reward_mode, cfg.dim == 3, &spec_shape);
+        if (feasible(64) && (cfg.reward_mode != UAVTRACK_REWARD_PMI || (spec_shape && N <= 20 && cfg.m_targets <= 10 && cfg.dim == 2))) {
             const long waves = (cfg.n_envs + envs_of(64) - 1) / envs_of(64);
             small_grid = waves <= 3L * (n_simd > 0 ? n_simd : 1024);
             waves64 = waves;
