@@ -61,6 +61,9 @@
 #ifndef UAVTRACK_FULL_BARRIER      // 0: the two step barriers order LDS only (s_waitcnt lgkmcnt(0); s_barrier) -- measured neutral
 #define UAVTRACK_FULL_BARRIER 1
 #endif
+#ifndef UAVTRACK_KNOCKOUT_COVERAGE // timing experiment only: 1 drops the coverage atomics (covered counts read 0)
+#define UAVTRACK_KNOCKOUT_COVERAGE 0
+#endif
 #ifndef UAVTRACK_KNOCKOUT_BARRIER  // timing experiments only (results are racy): 1 drops the second step barrier, 2 both
 #define UAVTRACK_KNOCKOUT_BARRIER 0
 #endif
@@ -293,7 +296,7 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
         cov = pk_fma(cov, splat(4.0f), pk_le_mask(d2, nscale, p.lt_dp2));
         if (kp % kCovPairs == kCovPairs - 1 || kp == MP - 1) {       // 12 digits < 2^24: exact in fp32
             const unsigned bits = (unsigned)cov.x | ((unsigned)cov.y << 1);
-            if (bits) atomicOr(&covw[covbase + kp / kCovPairs], bits);
+            if (bits && !UAVTRACK_KNOCKOUT_COVERAGE) atomicOr(&covw[covbase + kp / kCovPairs], bits);
             cov = splat(0.f);
         }
     }
