@@ -272,6 +272,8 @@ int uavtrack_create(const uavtrack_config *cfg, uavtrack_env **out)
         return fail("uavtrack_create: no workgroup geometry for n_uav=%d", cfg->n_uav);
     }
     env->base.E = env->geo.envs_per_wg;
+    env->geo_short = cfg->reward_mode == UAVTRACK_REWARD_PMI ? plan_geometry(*cfg, prop.multiProcessorCount * 4, false) : env->geo;
+    if (env->geo_short.wgs == 0 || env->geo_short.lds_bytes > 64 * 1024) env->geo_short = env->geo;
     if (env->geo.lds_bytes > 64 * 1024) {
         const size_t need = env->geo.lds_bytes;
         delete env;
@@ -597,7 +599,8 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
         p.covered = covered_t;
         p.done = done ? done + (size_t)t0 * c.n_envs : nullptr;
         p.tpos = env->tpos ? env->tpos + (size_t)t0 * c.n_envs * c.m_targets : nullptr;
-        HIP_TRY(timed_launch(env, UAVTRACK_PROF_ROLLOUT, st, [&] { return launch_rollout(env, p, st, pol.policy); }));
+        const Geometry *geo = n < kPmiShortLaunch ? &env->geo_short : &env->geo;
+        HIP_TRY(timed_launch(env, UAVTRACK_PROF_ROLLOUT, st, [&] { return launch_rollout(env, p, st, pol.policy, geo); }));
         // the actor of the next chunk starts from this chunk's last observation (a lane reads its own row
         // once, at launch start, before it writes anything: the scratch buffer may be reused in place)
         p.obs_in = obs_t + (size_t)(n - 1) * BN * UAVTRACK_OBS_DIM;
@@ -736,10 +739,10 @@ int uavtrack_run_actor(uavtrack_env *env, int32_t T, uint64_t seed, int32_t mode
     if (obs_in == obs && T > 1)
         return fail("uavtrack_run_actor: obs_in must not alias obs when T > 1 (pass the previous launch's last rows, "
                     "or a copy)");
-    if (rollout_lds_bytes(env, kPolicyActor) > 64 * 1024)
+    if (rollout_lds_bytes(env->geo, kPolicyActor) > 64 * 1024 || rollout_lds_bytes(env->geo_short, kPolicyActor) > 64 * 1024)
         return fail("uavtrack_run_actor: the step tables (%zu B) plus the actor's %zu B of LDS per workgroup exceed 64 KiB for "
                     "n_uav=%d, m_targets=%d; use uavtrack_actor_actions + uavtrack_step for this shape",
-                    env->geo.lds_bytes, rollout_lds_bytes(env, kPolicyActor) - env->geo.lds_bytes, env->cfg.n_uav, env->cfg.m_targets);
+                    env->geo.lds_bytes, rollout_lds_bytes(env->geo, kPolicyActor) - env->geo.lds_bytes, env->cfg.n_uav, env->cfg.m_targets);
     PolicyArgs pol;
     pol.policy = kPolicyActor; pol.obs_in = obs_in; pol.actions_out = actions_out; pol.seed = seed; pol.mode = mode;
     return run_steps(env, T, nullptr, obs, reward, terms, covered, done, ep_sums, stream, "uavtrack_run_actor", false, pol);

@@ -136,6 +136,10 @@ struct uavtrack_env {
     float *slab = nullptr;       // the one device allocation behind `state`
     uavtrack::StateBlock state;  // pointers into the slab (host-side view)
     uavtrack::Geometry geo;
+    // MAAC-R launches of fewer than kPmiShortLaunch steps: the 4-wave geometry (one pair-list reservation per workgroup-step
+    // on a quarter of the workgroups; the single-wavefront variant's block reservations pay off over many steps, and a
+    // launch that starts with an empty pool waits for its first one)
+    uavtrack::Geometry geo_short;
     uavtrack::PmiWeights pmi;
     int32_t n_cus = 0;           // compute units of the device (grid of the persistent scorer)
     float *actor_w = nullptr;    // device blob of uavtrack_set_actor_weights (actor.h layout)
@@ -167,12 +171,15 @@ struct uavtrack_env {
 namespace uavtrack {
 
 // step_kernel.hip
-Geometry plan_geometry(const uavtrack_config &cfg, int n_simd);
+Geometry plan_geometry(const uavtrack_config &cfg, int n_simd, bool allow_small_grid = true);
 enum { kPolicyGiven = 0, kPolicyGreedy = 1, kPolicyActor = 2 };   // where a rollout's actions come from
-hipError_t launch_rollout(const uavtrack_env *env, const StepParams &p, hipStream_t stream, int policy = kPolicyGiven);
-size_t rollout_lds_bytes(const uavtrack_env *env, int policy);   // dynamic LDS of a rollout launch with that policy
+// (geo: the launch geometry, default the handle's own; MAAC-R launches of a few steps use env->geo_short)
+hipError_t launch_rollout(const uavtrack_env *env, const StepParams &p, hipStream_t stream, int policy = kPolicyGiven,
+                          const Geometry *geo = nullptr);
+size_t rollout_lds_bytes(const Geometry &g, int policy);   // dynamic LDS of a rollout launch with that policy
 
 // pmi_kernel.hip
+constexpr int kPmiShortLaunch = 16;
 constexpr int kPmiMaxHidden = 256;                  // widest PMINetwork hidden layer the scorer is instantiated for
 inline int pmi_padded_hidden(int hidden) { return (hidden + 31) / 32 * 32; }   // the scorer's column-block granule
 void pack_pmi_blob(const float *abi_blob, float *device_order, int hidden);

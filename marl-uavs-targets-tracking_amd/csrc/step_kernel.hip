@@ -960,8 +960,8 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
                     pool_dummies((unsigned)__builtin_amdgcn_readfirstlane((int)pend_base_v), pend_size);
                     pend = false;
                 }
-                if (!pend) {
-                    pend_size = moved > kPoolBlock ? moved : kPoolBlock;
+                if (!pend) {     // (the launch's last step takes exactly what it needs: nothing left over to fill with dummies)
+                    pend_size = (moved > kPoolBlock || t + 1 == p.T) ? moved : kPoolBlock;
                     if (tid == 0) pend_base_v = atomicAdd(p.pair_count, pend_size);
                 }
                 const unsigned nbase = (unsigned)__builtin_amdgcn_readfirstlane((int)pend_base_v);   // (waits for the reservation: as a rule made a step or more ago)
@@ -1261,7 +1261,7 @@ KernelFn pick_kernel(int N, int M, int mode, bool z3, int *specialised, int poli
 
 }  // namespace
 
-Geometry plan_geometry(const uavtrack_config &cfg, int n_simd)
+Geometry plan_geometry(const uavtrack_config &cfg, int n_simd, bool allow_small_grid)
 {
     Geometry g;
     const int N = cfg.n_uav;
@@ -1313,7 +1313,8 @@ Geometry plan_geometry(const uavtrack_config &cfg, int n_simd)
         // sizes that variant is built for)
         int spec_shape = 0;
         pick_kernel(N, cfg.m_targets, cfg.reward_mode, cfg.dim == 3, &spec_shape);
-        if (feasible(64) && (cfg.reward_mode != UAVTRACK_REWARD_PMI || (spec_shape && N <= 20 && cfg.m_targets <= 10 && cfg.dim == 2))) {
+        if (allow_small_grid && feasible(64) &&
+            (cfg.reward_mode != UAVTRACK_REWARD_PMI || (spec_shape && N <= 20 && cfg.m_targets <= 10 && cfg.dim == 2))) {
             const long waves = (cfg.n_envs + envs_of(64) - 1) / envs_of(64);
             small_grid = waves <= 3L * (n_simd > 0 ? n_simd : 1024);
             waves64 = waves;
@@ -1334,23 +1335,24 @@ Geometry plan_geometry(const uavtrack_config &cfg, int n_simd)
     return g;
 }
 
-size_t rollout_lds_bytes(const uavtrack_env *env, int policy)
+size_t rollout_lds_bytes(const Geometry &g, int policy)
 {
-    size_t lds = env->geo.lds_bytes;
-    if (policy == kPolicyActor) lds += (size_t)(env->geo.wgs / 64) * kActorLdsFloats * sizeof(float);
+    size_t lds = g.lds_bytes;
+    if (policy == kPolicyActor) lds += (size_t)(g.wgs / 64) * kActorLdsFloats * sizeof(float);
     return lds;
 }
 
-hipError_t launch_rollout(const uavtrack_env *env, const StepParams &p, hipStream_t stream, int policy)
+hipError_t launch_rollout(const uavtrack_env *env, const StepParams &p, hipStream_t stream, int policy, const Geometry *geo)
 {
     int spec = 0;
+    const Geometry &g = geo ? *geo : env->geo;
     const bool allout = p.obs && p.reward && p.terms && p.covered && p.done;
     const bool extras = p.auto_reset || p.tpos;
-    KernelFn fn = pick_kernel(p.N, p.M, env->cfg.reward_mode, env->cfg.dim == 3, &spec, policy, allout, extras, env->geo.lone != 0);
-    const Geometry &g = env->geo;
+    KernelFn fn = pick_kernel(p.N, p.M, env->cfg.reward_mode, env->cfg.dim == 3, &spec, policy, allout, extras, g.lone != 0);
     StepParams q = p;
+    q.E = g.envs_per_wg;
     if (policy == kPolicyActor) q.actor_lds_off = (int32_t)g.lds_bytes;
-    hipLaunchKernelGGL(fn, dim3(g.groups), dim3(g.wgs), rollout_lds_bytes(env, policy), stream, q);
+    hipLaunchKernelGGL(fn, dim3(g.groups), dim3(g.wgs), rollout_lds_bytes(g, policy), stream, q);
     return hipGetLastError();
 }
 

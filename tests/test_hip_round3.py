@@ -322,3 +322,37 @@ def test_two_rank_shard_and_gather(uavtrack, tmp_path, backend):
     assert got.shape == (total, 5)
     np.testing.assert_array_equal(got, want)
     env.close()
+
+
+@pytest.mark.parametrize("box", [2000.0, 500.0])
+def test_pmi_long_launch_pooled_slots_equals_single_steps(uavtrack, pmi_state_dict, box):
+    """MAAC-R launches of >= 16 steps run on single-wavefront groups that take their pair-list slots from a private pool
+    (block reservations, UAV-granular block switches, dummy records the scorer skips); shorter launches and
+    uavtrack_step use the 4-wave geometry with one reservation per workgroup-step.  Both must give the same bits: one
+    40-step launch == 40 single steps (rewards, observations, terms, coverage, episode sums within rounding, final state),
+    in the reference box and in the dense one (many pairs per step: blocks above the default size, frequent switches)."""
+    B, N, M, T = 300, 20, 10, 40
+    cfg = uavtrack.EnvConfig(n_envs=B, n_uav=N, m_targets=M, cooperative=0.3, x_max=box, y_max=box,
+                             reward_mode=uavtrack.RewardMode.PMI)
+    a, b = uavtrack.BatchedUavEnv(cfg), uavtrack.BatchedUavEnv(cfg)
+    a.set_pmi(pmi_state_dict); b.set_pmi(pmi_state_dict)
+    a.reset(seed=17); b.reset(seed=17)
+    assert a.kernel_info()["workgroup"] == 64            # the long-launch geometry
+    act = torch.randint(0, 12, (T, B, N), dtype=torch.int32, device="cuda", generator=torch.Generator("cuda").manual_seed(2))
+    p0 = a.pmi_pairs_scored()
+    many = a.step_many(act)
+    pairs_many = a.pmi_pairs_scored() - p0
+    p0 = b.pmi_pairs_scored()
+    ep = torch.zeros(B, 5, device="cuda")
+    for t in range(T):
+        obs, rew, _ = b.step(act[t])
+        assert torch.equal(rew, many["reward"][t]), t
+        assert torch.equal(obs, many["obs"][t]), t
+        assert torch.equal(b.info["terms"], many["terms"][t]) and torch.equal(b.info["covered"], many["covered"][t]), t
+        ep[:, 0] += rew.mean(1); ep[:, 1:4] += b.info["terms"].mean(2).T; ep[:, 4] += b.info["covered"]
+    assert b.pmi_pairs_scored() - p0 == pairs_many > 0   # the same real pairs, whatever the dummies
+    torch.testing.assert_close(many["ep_sums"], ep, rtol=1e-5, atol=1e-5)
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert float((many["reward"] - (1 - 0.3) * 0).abs().max()) > 0      # (rewards are not all zero)
