@@ -788,13 +788,24 @@ def worker(args):
                           "fp32 matrix cores (peak 157.3 TFLOP/s); both figures are over the whole launch")
         default_workload = (world == 1 and args.reward == "raw" and args.policy == "given" and args.dim == 2 and args.box == 2000.0
                             and (B, N, M) == (4096, 20, 10))
+        # (the optional legs must never cost the run its line: a failure is reported in place)
+        def guarded(key, fn):
+            try:
+                return fn()
+            except Exception as exc:                      # noqa: BLE001 -- reported, not swallowed
+                import traceback
+                sys.stderr.write(f"bench.py: optional leg {key!r} failed:\n{traceback.format_exc()}")
+                return {"error": f"{type(exc).__name__}: {exc}"}
         if default_workload and not args.no_other_configs:
-            line["other_configs"] = other_configs(uavtrack, args, device)
+            line["other_configs"] = guarded("other_configs", lambda: other_configs(uavtrack, args, device))
         if world == 1 and not args.no_extras and args.reward != "pmi" and args.policy == "given":
-            line.update(extras(uavtrack, args, B, device, bytes_unit))
+            ex = guarded("extras", lambda: extras(uavtrack, args, B, device, bytes_unit))
+            line.update(ex if "error" not in ex else {"extras_error": ex["error"]})
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
-            line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+            cb = guarded("cpu_baseline", lambda: cpu_baseline(args, args.cpu_seconds))
+            line["cpu_baseline"] = cb
+            if "value" in cb:
+                cb["gpu_over_cpu"] = value / cb["value"]
         print(json.dumps(line), flush=True)
 
     if world > 1:
