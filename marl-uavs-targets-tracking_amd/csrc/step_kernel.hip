@@ -568,7 +568,11 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
     float *const own0 = reinterpret_cast<float *>(uenv + (i >> 1) * 6) + (i & 1);
     // (register-resident targets cost five registers: at 50 x 25 that is the difference between three and four waves per
     // SIMD -- 16.6 vs 17.4 G agent-steps/s at 8192 envs in 3-D -- so the larger shapes keep the LDS read-modify-write)
-    const bool one_target_per_lane = (LONE || (N_ > 0 && N_ <= 20)) && E * M <= nthreads;
+    // (... except in the plain rollout variant -- pre-sampled actions, every output, no extras, MAAC reward -- which has the
+    // five registers to spare at 128: 4.11-4.15 against 4.19-4.21 ms per 200 steps at 8192 x 50 x 25)
+    constexpr bool kRegTargets = LONE || (N_ > 0 && N_ <= 20) ||
+                                 (N_ > 0 && N_ <= 50 && MODE == UAVTRACK_REWARD_RAW && ALLOUT && !EXTRAS && POLICY == kPolicyGiven);
+    const bool one_target_per_lane = kRegTargets && E * M <= nthreads;
     const bool my_target = tid < envs_here * M;
     float *tgt = reinterpret_cast<float *>(ttab);
     float ttx = 0, tty = 0, ttc = 1, tts = 0, tth = 0;   // the lane's own target, resident across the T steps
