@@ -79,7 +79,7 @@ void drop_profile(uavtrack_env *env)
 template <typename F>
 hipError_t timed_launch(uavtrack_env *env, int cls, hipStream_t st, F &&launch)
 {
-    if (!env->profiling) return launch();
+    if (!env->profiling || env->prof.size() >= 65536) return launch();      // (bounded: a caller that never reads the profile leaks nothing further)
     uavtrack_env::ProfRec r{cls, nullptr, nullptr};
     hipError_t e = hipEventCreate(&r.a);
     if (e == hipSuccess) e = hipEventCreate(&r.b);
