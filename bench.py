@@ -502,17 +502,19 @@ def other_configs(uavtrack, args, device):
     out = []
     for name, over in (("configs[2] MAAC-R, PMI hidden 128", dict(reward="pmi", pmi_hidden=128, envs=4096, n_uav=20, m_targets=10, dim=2)),
                        ("configs[2] MAAC-R, PMI hidden 64 (PMINetwork's default)", dict(reward="pmi", pmi_hidden=64, envs=4096, n_uav=20, m_targets=10, dim=2)),
-                       ("configs[3] 3-D kinematics", dict(reward="raw", envs=8192, n_uav=50, m_targets=25, dim=3))):
+                       ("configs[3] 3-D kinematics", dict(reward="raw", envs=8192, n_uav=50, m_targets=25, dim=3)),
+                       # "also report a dense variant (box 500 m) as the PMI worst case"
+                       ("configs[2] MAAC-R dense variant (500 m box), PMI hidden 128", dict(reward="pmi", pmi_hidden=128, envs=4096, n_uav=20, m_targets=10, dim=2, box=500.0))):
         a = copy.copy(args)
+        a.policy, a.box = "given", 2000.0
         for k, v in over.items():
             setattr(a, k, v)
-        a.policy, a.box = "given", 2000.0
         a.cooperative = 0.0 if a.reward == "raw" else 0.3
         B, N, M = a.envs, a.n_uav, a.m_targets
         roof = roofline_leg(uavtrack, a, B, device)
         units = B * N * roof["T"]
         ent = {"config": name,
-               "workload": f"{B} envs x {N} UAVs x {M} targets, {a.dim}-D, "
+               "workload": f"{B} envs x {N} UAVs x {M} targets, {a.dim}-D, {a.box:.0f} m box, "
                            + (f"MAAC-R reciprocal (PMI H={a.pmi_hidden}) reward" if a.reward == "pmi" else "MAAC tracking reward"),
                "agent_steps_per_s": units / (roof["avg_ms"] * 1e-3), "agent_steps_per_s_at_median": units / (roof["median_ms"] * 1e-3),
                "geometry": roof["geometry"]}

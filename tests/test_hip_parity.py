@@ -997,8 +997,8 @@ def test_bench_contract_line(uavtrack):
     # back-to-back launches at loaded clocks: no host latency inside an event pair, no post-idle ramp (tools/drift.py)
     assert max(rf["launch_ms"]) < 1.12 * min(rf["launch_ms"])
     # the other single-GPU BASELINE configurations ride on the default line (--no-extras does not drop them)
-    oc = {c["config"].split(" ")[0] + (" H64" if "64" in c["config"] else ""): c for c in d["other_configs"]}
-    assert set(oc) == {"configs[2]", "configs[2] H64", "configs[3]"}
+    oc = {c["config"].split(" ")[0] + (" dense" if "dense" in c["config"] else " H64" if "hidden 64" in c["config"] else ""): c for c in d["other_configs"]}
+    assert set(oc) == {"configs[2]", "configs[2] H64", "configs[3]", "configs[2] dense"}
     for key, c in oc.items():
         r2 = c["roofline"]
         assert r2["launches_timed"] >= 10 and r2["launches_untimed_before"] >= 3 and 0.0 < r2["frac"] < 1.0
@@ -1006,7 +1006,8 @@ def test_bench_contract_line(uavtrack):
             assert r2["bound"] == "mfma" and r2["unit"] == "TFLOP/s" and r2["peak"] == 2500.0 and "pmi_score_t3_kernel" in r2["kernel"]
             assert 0.1 < r2["pairs_per_agent_step"] < 1.0 and r2["scorer_ms_per_launch"] < r2["avg_launch_ms"]
             assert r2["fp32_equivalent_over_fp32_mfma_peak"] > 1.0          # past what the fp32 matrix pipe could do at all
-            assert c["agent_steps_per_s"] > (6.0e9 if "H64" in key else 4.0e9)
+            assert c["agent_steps_per_s"] > (8.0e9 if "H64" in key else 3.0e9 if "dense" in key else 6.0e9)
+            assert (r2["pairs_per_agent_step"] > 0.4) == ("dense" in key)
         else:
             assert r2["bound"] == "hbm" and abs(r2["algorithmic_bytes_per_agent_step"] - 124.1) < 1e-9
             assert r2["agent_steps_per_launch"] == 8192 * 50 * 200 and r2["frac"] > 0.24
