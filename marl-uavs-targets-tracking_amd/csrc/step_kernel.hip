@@ -774,7 +774,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
                         nbmask |= (unsigned long long)(d2 <= p.dp2 ? 1u : 0u) << j;
                     }
             } else {
-                sweep_fast<N_, M_, Z3, kMask, LONE ? (MODE == UAVTRACK_REWARD_PMI ? UAVTRACK_LDS_PREFETCH_PMI : UAVTRACK_LDS_PREFETCH) : 0>(p, N, M, i, rowNew, rowOld, tenv, tzrow, covw, cbuf + e * CW,
+                sweep_fast<N_, M_, Z3, kMask, LONE ? ((MODE == UAVTRACK_REWARD_PMI || POLICY != kPolicyGiven) ? UAVTRACK_LDS_PREFETCH_PMI : UAVTRACK_LDS_PREFETCH) : 0>(p, N, M, i, rowNew, rowOld, tenv, tzrow, covw, cbuf + e * CW,
                                               x, y, z, c, s, ai, xo, yo, zo, co, so, ao, acc, nbmask);
             }
 
@@ -1236,6 +1236,10 @@ KernelFn pick_mode(int mode, bool z3, int policy, bool allout, bool extras, bool
     if constexpr (N_ > 0 && N_ <= 20 && M_ <= 10) {       // the shapes sweep_fast's prefetch is written for
         if (policy == kPolicyGiven && allout && !extras && lone && !z3)
             return pick_reward<N_, M_, kPolicyGiven, true, false, true>(mode, false);
+        // the fused actor rollout on single-wavefront groups: wave fences for barriers and, under MAAC-R, pair-list slots
+        // from the pool (the 4-wave emission path would make one reservation per workgroup-step on four times the groups)
+        if (policy == kPolicyActor && !extras && lone && !z3)
+            return pick_reward<N_, M_, kPolicyActor, false, false, true>(mode, false);
     }
     if (policy == kPolicyGreedy)
         return extras ? pick_reward<N_, M_, kPolicyGreedy, false, true>(mode, z3) : pick_reward<N_, M_, kPolicyGreedy, false, false>(mode, z3);
