@@ -38,7 +38,7 @@ def case(c, rng):
     box = float(rng.choice([150.0, 600.0, 2000.0]))
     mode = int(rng.choice([0, 1, 2]))                       # RAW, MEAN, PMI
     H = int(rng.choice([64, 128, 128, 32, 96, 100, 160]))     # (other widths are padded to the scorer's 32-column blocks)
-    T = int(rng.choice([1, 2, 7, 13]))
+    T = int(rng.choice([1, 2, 7, 13, 20, 33]))     # (>= 16: MAAC-R launches on single-wavefront groups take pooled pair-list slots)
     off = int(rng.choice([0, 5, 10 ** 10]))
     dim = int(rng.choice([2, 2, 2, 3]))
     wgs = int(rng.choice([0, 0, 64, 128, 256, 512]))          # 0: the library's own choice

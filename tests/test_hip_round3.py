@@ -324,14 +324,14 @@ def test_two_rank_shard_and_gather(uavtrack, tmp_path, backend):
     env.close()
 
 
-@pytest.mark.parametrize("box", [2000.0, 500.0])
-def test_pmi_long_launch_pooled_slots_equals_single_steps(uavtrack, pmi_state_dict, box):
+@pytest.mark.parametrize("N,M,box", [(20, 10, 2000.0), (20, 10, 500.0), (10, 10, 700.0), (5, 3, 400.0)])
+def test_pmi_long_launch_pooled_slots_equals_single_steps(uavtrack, pmi_state_dict, N, M, box):
     """MAAC-R launches of >= 16 steps run on single-wavefront groups that take their pair-list slots from a private pool
     (block reservations, UAV-granular block switches, dummy records the scorer skips); shorter launches and
     uavtrack_step use the 4-wave geometry with one reservation per workgroup-step.  Both must give the same bits: one
     40-step launch == 40 single steps (rewards, observations, terms, coverage, episode sums within rounding, final state),
     in the reference box and in the dense one (many pairs per step: blocks above the default size, frequent switches)."""
-    B, N, M, T = 300, 20, 10, 40
+    B, T = 300, 40        # (the three swarm shapes the single-wavefront variant is built for: 3, 6 and 12 environments per wavefront)
     cfg = uavtrack.EnvConfig(n_envs=B, n_uav=N, m_targets=M, cooperative=0.3, x_max=box, y_max=box,
                              reward_mode=uavtrack.RewardMode.PMI)
     a, b = uavtrack.BatchedUavEnv(cfg), uavtrack.BatchedUavEnv(cfg)
