@@ -317,9 +317,9 @@ def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, en
         summaries = [h.wait() for h in pending]
         assert all(s.shape[0] == total_envs for s in summaries)
     torch.cuda.synchronize(device)
+    wall = time.perf_counter() - t0       # this rank's K steps (and every gather it took part in) are done; the caller takes the MAX over ranks
     if gather is not None:
-        dist.barrier()
-    wall = time.perf_counter() - t0
+        dist.barrier()                    # closing bracket: no rank leaves the region before the slowest has stopped its clock
     info = env.kernel_info()
     env.close()
     if warm is not None:
