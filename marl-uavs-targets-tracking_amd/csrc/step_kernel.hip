@@ -61,6 +61,12 @@
 #ifndef UAVTRACK_FULL_BARRIER      // 0: the two step barriers order LDS only (s_waitcnt lgkmcnt(0); s_barrier) -- measured neutral
 #define UAVTRACK_FULL_BARRIER 1
 #endif
+#ifndef UAVTRACK_SYM_DUP           // 0: every lane sweeps all peers for the duplicate term (A/B measurements)
+#define UAVTRACK_SYM_DUP 1
+#endif
+#ifndef UAVTRACK_REG_TARGETS_50
+#define UAVTRACK_REG_TARGETS_50 0
+#endif
 #ifndef UAVTRACK_KNOCKOUT_COVERAGE // timing experiment only: 1 drops the coverage atomics (covered counts read 0)
 #define UAVTRACK_KNOCKOUT_COVERAGE 0
 #endif
@@ -210,6 +216,11 @@ __device__ __host__ __forceinline__ int tstride_of(int m)
     return (s * 4) % 64 == 0 ? s + 1 : s;
 }
 
+// ---- symmetric duplicate term (MAAC reward mode): per environment the post-move poses once more as plain arrays of
+// length N + N/2 (entry N + j repeats entry j, so "peer i + k" needs no wrap-around), and 2 N fixed-point accumulators
+__device__ __host__ __forceinline__ int sym_pose_len(int n) { return n + n / 2 + 1; }   // (+1: the packed evaluation of the last peer reads its neighbour)
+__device__ __host__ __forceinline__ int sym_words(int n, bool z3) { return sym_pose_len(n) * (z3 ? 3 : 2) + 2 * n; }
+
 // scalar views of the pair rows (slow paths, table fills)
 struct UavRow { float x, y, c, s, a, z; };
 __device__ __forceinline__ UavRow uav_elem(const float4 *rows, int j)   // rows: env base + copy * 3
@@ -235,7 +246,7 @@ __device__ __host__ constexpr bool act_bias_shape(int n_spec) { return n_spec > 
 // Pair sweeps of one UAV, fast path: two agents per packed instruction, no per-agent
 // `j != i` test (self terms are subtracted afterwards).  The uav.py:165/179 weight is 1
 // here (see sweep_weighted).
-template <int N_, int M_, bool Z3, bool NB, int PF>
+template <int N_, int M_, bool Z3, bool NB, int PF, bool SYM = false>
 __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, int i,
                                            const float4 *__restrict__ rowNew, const float4 *__restrict__ rowOld,
                                            const float4 *__restrict__ trow, const v2f *__restrict__ tzrow,
@@ -326,20 +337,26 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
         const v2f dxm = (v2f){m0.x, m0.y} - xi2, dym = (v2f){m0.z, m0.w} - yi2;
         v2f d2n = pk_fma(dyn, dyn, dxn * dxn), d2m = pk_fma(dym, dym, dxm * dxm);
         if (Z3) {
-            const float4 n2 = rowNew[jp * 6 + 2];
-            const v2f dzn = (v2f){n2.z, n2.w} - zi2, dzm = (v2f){m2.z, m2.w} - zi2;
-            d2n = pk_fma(dzn, dzn, d2n);
+            const v2f dzm = (v2f){m2.z, m2.w} - zi2;
             d2m = pk_fma(dzm, dzm, d2m);
+            if (!SYM) {
+                const float4 n2 = rowNew[jp * 6 + 2];
+                const v2f dzn = (v2f){n2.z, n2.w} - zi2;
+                d2n = pk_fma(dzn, dzn, d2n);
+            }
         }
         if (NBF)       // <= 12 pairs: the same packed mask + base-4 digits as the coverage bits (bit order fixed up below)
             nbf = pk_fma(nbf, splat(4.0f), pk_le_mask(d2n, nscale, p.le_dp2));
         else if (NB)   // cooperative modes (N <= 64): neighbours (d <= dp on post-move poses, uav.py:278) as a bit mask
             nbmask |= ((unsigned long long)(d2n.x <= p.dp2 ? 1u : 0u) | (unsigned long long)(d2n.y <= p.dp2 ? 2u : 0u)) << (2 * jp);
-        const v2f w = pk_fma((v2f){fast_sqrt(d2n.x), fast_sqrt(d2n.y)}, splat(-p.exp_k1), splat(p.exp_k0));
 #if UAVTRACK_LE_ASM
-        dup = pk_fma(pk_le_mask(d2n, nscale, p.le_two_dp2), (v2f){fast_exp2(w.x), fast_exp2(w.y)}, dup);
+        if (!SYM) {   // (SYM: the duplicate term is shared between the two UAVs of a pair, see sym_dup)
+            const v2f w = pk_fma((v2f){fast_sqrt(d2n.x), fast_sqrt(d2n.y)}, splat(-p.exp_k1), splat(p.exp_k0));
+            dup = pk_fma(pk_le_mask(d2n, nscale, p.le_two_dp2), (v2f){fast_exp2(w.x), fast_exp2(w.y)}, dup);
+        }
         const v2f mm = pk_le_mask(d2m, nscale, p.le_dc2);
 #else
+        const v2f w = pk_fma((v2f){fast_sqrt(d2n.x), fast_sqrt(d2n.y)}, splat(-p.exp_k1), splat(p.exp_k0));
         dup += (v2f){d2n.x <= p.two_dp2 ? fast_exp2(w.x) : 0.0f, d2n.y <= p.two_dp2 ? fast_exp2(w.y) : 0.0f};
         const v2f mm = {d2m.x <= p.dc2 ? 1.0f : 0.0f, d2m.y <= p.dc2 ? 1.0f : 0.0f};
 #endif
@@ -374,6 +391,65 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
     a.scU = fmaf(-ci, a.cntU, sc.x + sc.y - ms * (odd ? ci : co));
     a.ssU = fmaf(-si, a.cntU, ss.x + ss.y - ms * (odd ? si : so));
     a.saU = fmaf(-ai, a.cntU, sa_all - ms * (odd ? ai : ao));
+}
+
+// The duplicate-tracking term (uav.py:214-229) is symmetric on the post-move poses: g(d_ij) enters UAV i's sum and UAV j's.
+// Each lane evaluates only the peers i + 1 .. i + N/2 (cyclically: a balanced half of the pair matrix), adds the value to its
+// own running sum and, through the LDS, to the partner's accumulator -- half the square roots and exponentials of the full
+// sweep.  The accumulators are FIXED-POINT integers (g * 2^sym_bits, at most e * N * 2^sym_bits < 2^32): integer addition
+// commutes, so the LDS atomics leave the same bits whatever order the wavefronts arrive in (a float accumulation would
+// not), and the quantisation (2^-22 per term at N = 50) is far below the fp32 rounding of the sum it replaces.  The
+// accumulator array has 2 N entries: lane i adds to entry i + k without wrapping and reads entries i and i + N.
+// Even N: the opposite peer (k = N/2) is evaluated by both ends, each keeping it for itself.
+template <int N_, bool Z3>
+__device__ __forceinline__ unsigned sym_dup(const StepParams &p, int N, int i, const float *__restrict__ sx, const float *__restrict__ sy,
+                                            const float *__restrict__ sz, unsigned *__restrict__ dacc, float xi, float yi, float zi)
+{
+    const int n = N_ > 0 ? N_ : N;
+    const int KP = (n - 1) / 2;                    // peers whose value is shared with the partner
+    const v2f xi2 = splat(xi), yi2 = splat(yi), zi2 = splat(zi), nscale = splat(p.le_neg_scale);
+    unsigned own = 0;
+    struct P2 { v2f x, y, z; };
+    auto load2 = [&](int k) {                      // poses of peers i + k and i + k + 1
+        P2 q;
+        q.x = (v2f){sx[i + k], sx[i + k + 1]};
+        q.y = (v2f){sy[i + k], sy[i + k + 1]};
+        q.z = Z3 ? (v2f){sz[i + k], sz[i + k + 1]} : splat(0.f);
+        return q;
+    };
+    auto eval2 = [&](const P2 &q) {                // fixed-point g of each
+        const v2f dx = q.x - xi2, dy = q.y - yi2;
+        v2f d2 = pk_fma(dy, dy, dx * dx);
+        if (Z3) { const v2f dz = q.z - zi2; d2 = pk_fma(dz, dz, d2); }
+        const v2f w = pk_fma((v2f){fast_sqrt(d2.x), fast_sqrt(d2.y)}, splat(-p.exp_k1), splat(p.sym_k0));
+        const v2f g = pk_le_mask(d2, nscale, p.le_two_dp2) * (v2f){fast_exp2(w.x), fast_exp2(w.y)};
+        return make_uint2((unsigned)g.x, (unsigned)g.y);
+    };
+    // (the poses of the next two peers are requested before the current two are evaluated: the LDS round trip, the
+    // square roots and the exponentials of consecutive iterations overlap)
+    constexpr int UK = (N_ > 0 && (N_ - 1) / 2 <= 10) ? 5 : 4;     // pairs of peers per unrolled body
+    const int last = KP + ((n & 1) == 0 ? 1 : 0);  // last peer index that is evaluated at all
+    P2 cur = load2(1);
+#pragma unroll UK
+    for (int k = 1; k + 1 <= KP; k += 2) {
+        P2 nxt = cur;
+        if (k + 2 <= last) nxt = load2(k + 2);
+        const uint2 q = eval2(cur);
+        own += q.x + q.y;
+        atomicAdd(&dacc[i + k], q.x);
+        atomicAdd(&dacc[i + k + 1], q.y);
+        cur = nxt;
+    }
+    if (KP & 1) {                                  // one shared peer left (`cur` holds it); with even N its neighbour is the opposite peer
+        const uint2 q = eval2(cur);                // (entry i + KP + 1 <= i + N/2 exists in the doubled arrays either way)
+        own += q.x;
+        atomicAdd(&dacc[i + KP], q.x);
+        if ((n & 1) == 0) own += q.y;              // k = N/2: kept, not shared
+    } else if ((n & 1) == 0) {
+        const uint2 q = eval2(cur);                // k = N/2 alone (its pair partner k + 1 is past the half: ignored)
+        own += q.x;
+    }
+    return own;
 }
 
 // Literal form with the uav.py:165/179 weight min(dist((rel_x, rel_y), (abs_x, abs_y)), 1).
@@ -488,6 +564,10 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
     unsigned *covw = reinterpret_cast<unsigned *>(fb);   // [2][E * CW] (+ 2 words, MAAC-R pair emission; + E words, automatic reset)
     unsigned *rstw = covw + 2 * E * CW + 2;              // [E] 0, or 1 + the episode number an environment is being reset to
     float *climb_l = reinterpret_cast<float *>(rstw + E); // (3-D) [2][UAVTRACK_MAX_CLIMB] cos / sin of the climb angles
+    // symmetric duplicate term (MAAC reward mode, sym_dup): [E][x | y | (z) | 2 N accumulators]
+    constexpr bool kSym = UAVTRACK_SYM_DUP && MODE == UAVTRACK_REWARD_RAW;
+    float *symbase = climb_l + (Z3 ? 2 * UAVTRACK_MAX_CLIMB : 0);
+    const int symlen = sym_pose_len(N), symstride = sym_words(N, Z3);
 
     const int grp = xcd_group(blockIdx.x, gridDim.x);
     const int env0 = grp * E;
@@ -571,7 +651,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
     // (... except in the plain rollout variant -- pre-sampled actions, every output, no extras, MAAC reward -- which has the
     // five registers to spare at 128: 4.11-4.15 against 4.19-4.21 ms per 200 steps at 8192 x 50 x 25)
     constexpr bool kRegTargets = LONE || (N_ > 0 && N_ <= 20) ||
-                                 (N_ > 0 && N_ <= 50 && MODE == UAVTRACK_REWARD_RAW && ALLOUT && !EXTRAS && POLICY == kPolicyGiven);
+                                 (UAVTRACK_REG_TARGETS_50 && N_ > 0 && N_ <= 50 && MODE == UAVTRACK_REWARD_RAW && ALLOUT && !EXTRAS && POLICY == kPolicyGiven);
     const bool one_target_per_lane = kRegTargets && E * M <= nthreads;
     const bool my_target = tid < envs_here * M;
     float *tgt = reinterpret_cast<float *>(ttab);
@@ -743,6 +823,17 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
             if (GIVEN && t + 1 < p.T) act_next = *at(p.actions + row + BN, g32 * 4u);   // prefetch next step's action
             if (i == 0)
                 for (int w = 0; w < CW; ++w) covw[cbuf + e * CW + w] = 0;
+            if (kSym) {      // post-move pose into the plain arrays (entry i + N repeats entry i), accumulators cleared
+                float *sp = symbase + e * symstride;
+                unsigned *dq = reinterpret_cast<unsigned *>(sp + (Z3 ? 3 : 2) * symlen);
+                sp[i] = x; sp[symlen + i] = y;
+                if (Z3) sp[2 * symlen + i] = z;
+                if (2 * i <= N) {
+                    sp[N + i] = x; sp[symlen + N + i] = y;
+                    if (Z3) sp[2 * symlen + N + i] = z;
+                }
+                dq[i] = 0; dq[N + i] = 0;
+            }
         }
         if (UAVTRACK_KNOCKOUT_BARRIER < 2) UAVTRACK_STEP_BARRIER();
 
@@ -755,6 +846,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
         // sweep as one 64-bit mask
         constexpr bool kMask = (MODE != UAVTRACK_REWARD_RAW) && N_ > 0 && N_ <= 64;
         unsigned long long nbmask = 0;
+        unsigned sym_own = 0;                       // (kSym) this lane's own half of the duplicate-term pairs, fixed point
         if (active) {
             Acc acc;
             // weight of uav.py:165 can be < 1 only near the origin (|rel| <= 1, so |abs| < 2 is necessary).  The branch
@@ -774,8 +866,13 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
                         nbmask |= (unsigned long long)(d2 <= p.dp2 ? 1u : 0u) << j;
                     }
             } else {
-                sweep_fast<N_, M_, Z3, kMask, LONE ? ((MODE == UAVTRACK_REWARD_PMI || POLICY != kPolicyGiven) ? UAVTRACK_LDS_PREFETCH_PMI : UAVTRACK_LDS_PREFETCH) : 0>(p, N, M, i, rowNew, rowOld, tenv, tzrow, covw, cbuf + e * CW,
+                sweep_fast<N_, M_, Z3, kMask, LONE ? ((MODE == UAVTRACK_REWARD_PMI || POLICY != kPolicyGiven) ? UAVTRACK_LDS_PREFETCH_PMI : UAVTRACK_LDS_PREFETCH) : 0, kSym>(p, N, M, i, rowNew, rowOld, tenv, tzrow, covw, cbuf + e * CW,
                                               x, y, z, c, s, ai, xo, yo, zo, co, so, ao, acc, nbmask);
+            }
+            if (kSym) {      // every active lane, whichever sweep it took: its partners count on its half of the pairs
+                const float *sp = symbase + e * symstride;
+                unsigned *dq = const_cast<unsigned *>(reinterpret_cast<const unsigned *>(sp + (Z3 ? 3 : 2) * symlen));
+                sym_own = sym_dup<N_, Z3>(p, N, i, sp, sp + symlen, sp + 2 * symlen, dq, x, y, z);
             }
 
             // ---- P3: local state (uav.py:156-190)
@@ -826,14 +923,14 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
             //   d < 0: -0.5 -> -1;  0 <= d < dp: -0.5 (dp - d) / dp -> d / dp - 1;  d >= dp: 0 -> 0   ==  clamp(d / dp, 0, 1) - 1
             bp = __builtin_amdgcn_fmed3f(d_bdr * p.inv_dp, 0.0f, 1.0f) - 1.0f;
             tt = __builtin_amdgcn_fmed3f(acc.trk, 0.0f, p.tt_ceil) * p.inv_tt_ceil;
-            dupn = (__builtin_amdgcn_fmed3f(acc.dup * -0.5f, p.dup_floor, 0.0f) - p.dup_floor) * p.inv_dup - 1.0f;
+            if (!kSym) dupn = (__builtin_amdgcn_fmed3f(acc.dup * -0.5f, p.dup_floor, 0.0f) - p.dup_floor) * p.inv_dup - 1.0f;
 #else
             float bpun = (d_bdr >= 0.0f) ? ((d_bdr < p.dp) ? -0.5f * (p.dp - d_bdr) * p.inv_dp : 0.0f) : -0.5f;
             tt = fminf(fmaxf(acc.trk, 0.0f), p.tt_ceil) * p.inv_tt_ceil;
             bp = (fminf(fmaxf(bpun, -0.5f), 0.0f) + 0.5f) * 2.0f - 1.0f;
             dupn = (fminf(fmaxf(acc.dup * -0.5f, p.dup_floor), 0.0f) - p.dup_floor) * p.inv_dup - 1.0f;
 #endif
-            raw = p.alpha * tt + p.beta * bp + p.gamma * dupn;
+            if (!kSym) raw = p.alpha * tt + p.beta * bp + p.gamma * dupn;      // (kSym: behind the barrier, once the partners' halves are in)
             if (MODE != UAVTRACK_REWARD_RAW) rawl[e * (N + 1) + i] = raw;
         }
         if (kPipeEmit && tid == 0) {
@@ -847,6 +944,12 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
 
         // ---- P4: cooperative reward, coverage, outputs
         if (active) {
+            if (kSym) {      // duplicate term: own half + what the partners added to this UAV's two accumulator entries
+                const unsigned *dq = reinterpret_cast<const unsigned *>(symbase + e * symstride + (Z3 ? 3 : 2) * symlen);
+                const float dsum = (float)(sym_own + dq[i] + dq[N + i]) * p.sym_inv;
+                dupn = (__builtin_amdgcn_fmed3f(dsum * -0.5f, p.dup_floor, 0.0f) - p.dup_floor) * p.inv_dup - 1.0f;
+                raw = p.alpha * tt + p.beta * bp + p.gamma * dupn;
+            }
             float r = raw;
             if (MODE == UAVTRACK_REWARD_MEAN) {
                 if (p.coop != 0.0f && kMask) {   // uav.py:293-310: walk the set bits of the neighbour mask, ascending j
@@ -1204,7 +1307,7 @@ size_t lds_bytes_for(int E, int N, int M, bool z3)
     const size_t CW = cov_words(M), MP = pairs_of(M);
     const size_t f4 = (size_t)E * ustride_of(N) + (size_t)E * tstride_of(M);
     const size_t f = (size_t)E * M + (size_t)E * (N + 1) + (z3 ? (size_t)E * MP * 2 : 0) + (size_t)E * M + 2 * E * CW + 2 + E +
-                     (z3 ? 2 * UAVTRACK_MAX_CLIMB : 0);
+                     (z3 ? 2 * UAVTRACK_MAX_CLIMB : 0) + (size_t)E * sym_words(N, z3);
     return (f4 * 16 + f * 4 + 15) & ~(size_t)15;   // ustride >= 3 N float4 per env, so ep_sums staging (E N float4) fits
 }
 
