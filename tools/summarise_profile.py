@@ -19,7 +19,9 @@ src = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/prof_{tag}"
 key = sys.argv[3] if len(sys.argv) > 3 else None     # e.g. 4096x20x10_T200 -> profiles/traffic.json
 os.makedirs("profiles", exist_ok=True)
 
-stats = glob.glob(f"{src}/trace/**/*_kernel_stats.csv", recursive=True)
+# (gpurun merges every call's files into the same directory: take the newest file of each pass)
+newest = lambda pat: sorted(glob.glob(pat, recursive=True), key=os.path.getmtime)[-1:]
+stats = newest(f"{src}/trace/**/*_kernel_stats.csv")
 kern = {}
 if stats:
     shutil.copy(stats[0], f"profiles/{tag}_kernel_stats.csv")
@@ -29,7 +31,7 @@ if stats:
 
 pmc = defaultdict(lambda: defaultdict(list))
 meta = {}
-for f in glob.glob(f"{src}/pmc_*/**/*_counter_collection.csv", recursive=True):
+for f in [g for d in sorted(glob.glob(f"{src}/pmc_*")) if os.path.isdir(d) for g in newest(f"{d}/**/*_counter_collection.csv")]:
     per_dispatch = defaultdict(float)
     names = {}
     for row in csv.DictReader(open(f)):
