@@ -425,14 +425,16 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
     const size_t HP = (size_t)hp, n_dev = 12 * HP + 3 * HP + 3 * HP * HP + HP + HP + 1;
     const size_t x6_off = (n_dev + 3) & ~(size_t)3, x6_len = pmi_x6_floats(hp);     // the bf16 planes, 16-B aligned
     const size_t h3_off = x6_off + x6_len, h3_len = pmi_h3_floats(hp);               // the f16 planes behind them
-    const size_t l1_off = h3_off + h3_len, l1_len = pmi_l1_floats(hp);               // ... and the branch layers' f16 planes
+    const size_t l1_off = h3_off + h3_len, l1_len = pmi_l1_floats(hp);               // ... the branch layers' f16 planes
+    const size_t t3_off = l1_off + l1_len, t3_len = h3_len;                           // ... and fc1 block-scaled (pmi_score_t3_kernel)
     if (env->pmi.n_floats != n_dev) {
         HIP_TRY(hipStreamSynchronize(st));
         if (env->pmi.blob) (void)hipFree(env->pmi.blob);
         env->pmi = PmiWeights();
-        HIP_TRY(dmalloc(&env->pmi.blob, l1_off + l1_len));
+        HIP_TRY(dmalloc(&env->pmi.blob, t3_off + t3_len));
     }
     bool h3_ok = h3_len != 0;
+    float s1 = 1.0f, tw = 1.0f;
     {   // fc1 goes up in the scorer's register order; the copy has completed before `packed` dies
         std::vector<float> padded(n_dev, 0.0f), packed(n_dev);
         const float *src = folded;
@@ -470,7 +472,7 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
             const double vr = 1.0 + c.t_v_max / c.u_v_max, pos = 4.0 * std::fmax(c.x_max, c.y_max) / c.dc;
             const double xb[12] = {1, 1, 4, 4, 1, 1, 1, vr * vr, vr * vr, pos * pos, pos * pos, 1};
             const float *pw = padded.data();
-            double act_max = 0.0, w_max = 0.0;
+            double act_max = 0.0, w_max = 0.0, w1_max = 0.0;
             const int fan[3] = {5, 4, 3};
             int k0 = 0;
             for (int br = 0; br < 3; ++br) {              // W[fan][HP] then b[HP]
@@ -482,23 +484,45 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
                 pw += (size_t)(fan[br] + 1) * HP;
                 k0 += fan[br];
             }
-            for (size_t k = 0; k < 3 * HP * HP; ++k) w_max = std::fmax(w_max, std::fabs(pw[k]));
+            for (size_t k = 0; k < 3 * HP * HP; ++k) w1_max = std::fmax(w1_max, std::fabs(pw[k]));
+            w_max = w1_max;
             for (size_t k = 0; k < 15 * HP; ++k) w_max = std::fmax(w_max, std::fabs(padded[k]));      // the branch layers (MFMA operands of pmi_score_t3_kernel)
             w_max = std::fmax(w_max, pos * pos);                                                         // ... and their inputs
             h3_ok = std::isfinite(act_max) && act_max < 32000.0 && w_max < 32000.0;
+            // Block scales of the t3 planes, powers of two: T * max |fc1 weight| just below 32000 (the weights are known
+            // exactly); S1 * (activation bound) below 512 -- the bound comes from nominal observation ranges, and the
+            // uav.py:165 weight lets a UAV next to the origin exceed them, so the activations keep a factor 128 of
+            // headroom to f16's 65504 (the unscaled h3 planes have 65504 / bound).  Remainders x - f16(x) of values within
+            // 2^-12 (activations) / 2^-18 (weights) of those sizes are normal f16 numbers.
+            auto scale_for = [](double bound, double target) {
+                int e = 15;
+                if (bound > 0.0) e = (int)std::floor(std::log2(target / bound));
+                return std::ldexp(1.0f, e < -6 ? -6 : (e > 15 ? 15 : e));
+            };
+            s1 = scale_for(act_max, 512.0);
+            tw = scale_for(w1_max, 32000.0);
         }
         std::vector<uint16_t> planes1(l1_len * 2);
         if (h3_ok) {
             pack_pmi_h3(padded.data(), planes3.data(), hp);
             HIP_TRY(hipMemcpyAsync(env->pmi.blob + h3_off, planes3.data(), h3_len * 4, hipMemcpyHostToDevice, st));
-            pack_pmi_l1(padded.data(), planes1.data(), hp);
+            pack_pmi_l1(padded.data(), planes1.data(), hp, s1);
             HIP_TRY(hipMemcpyAsync(env->pmi.blob + l1_off, planes1.data(), l1_len * 4, hipMemcpyHostToDevice, st));
+        }
+        std::vector<uint16_t> planes3t;
+        if (h3_ok) {
+            planes3t.resize(t3_len * 2);
+            pack_pmi_t3(padded.data(), planes3t.data(), hp, tw);
+            HIP_TRY(hipMemcpyAsync(env->pmi.blob + t3_off, planes3t.data(), t3_len * 4, hipMemcpyHostToDevice, st));
         }
         HIP_TRY(hipStreamSynchronize(st));
     }
     env->pmi.x6 = x6_len ? env->pmi.blob + x6_off : nullptr;
     env->pmi.h3 = h3_ok ? env->pmi.blob + h3_off : nullptr;
     env->pmi.l1 = h3_ok ? env->pmi.blob + l1_off : nullptr;
+    env->pmi.t3 = h3_ok ? env->pmi.blob + t3_off : nullptr;
+    env->pmi.t3_s1 = s1;
+    env->pmi.t3_t = tw;
     env->pmi.hidden = hp;
     env->pmi.n_floats = n_dev;
     if (ensure_pmi_scratch(env, 1, st)) return 1;

@@ -115,7 +115,9 @@ struct PmiWeights {
     const void *x6 = nullptr; // -> into blob: fc1 as three bf16 planes in MFMA operand order (pack_pmi_x6), or null
     const void *h3 = nullptr; // -> into blob: fc1 as two f16 planes (hi, lo * 2^11) in MFMA operand order (pack_pmi_h3), or null
                               //    (also null when the network's weights / activation bounds do not fit f16's range)
-    const void *l1 = nullptr; // -> into blob: the branch layers as f16 planes in MFMA A-operand order (pack_pmi_l1), with h3
+    const void *l1 = nullptr; // -> into blob: the branch layers as f16 planes in MFMA A-operand order (pack_pmi_l1), with t3
+    const void *t3 = nullptr; // -> into blob: fc1 block-scaled as two f16 planes (f16(T w), remainder) for pmi_score_t3_kernel, with h3
+    float t3_s1 = 1.0f, t3_t = 1.0f;   // the powers of two folded into the branch layers (S1) and fc1 (T) of the t3 planes
     int32_t hidden = 0;
     size_t n_floats = 0;
 };
@@ -190,8 +192,9 @@ inline size_t pmi_x6_floats(int hp) { return hp >= kPmiX6MinHidden && hp <= kPmi
 void pack_pmi_x6(const float *abi_blob, uint16_t *planes, int hidden);
 inline size_t pmi_h3_floats(int hp) { return hp >= kPmiX6MinHidden && hp <= kPmiX6MaxHidden ? (size_t)3 * hp * hp : 0; }   // 2 planes x 2 B
 void pack_pmi_h3(const float *abi_blob, uint16_t *planes, int hidden);
-inline size_t pmi_l1_floats(int hp) { return pmi_h3_floats(hp) ? (size_t)(hp / 32) * 3 * 2 * 64 * 8 / 2 : 0; }   // [w][branch][plane][lane][8] x 2 B
-void pack_pmi_l1(const float *abi_blob, uint16_t *planes, int hidden);
+void pack_pmi_t3(const float *abi_blob, uint16_t *planes, int hidden, float T);             // (size: pmi_h3_floats)
+inline size_t pmi_l1_floats(int hp) { return pmi_h3_floats(hp) ? (size_t)(hp / 32) * 3 * 3 * 64 * 8 / 2 : 0; }   // [w][branch][3 planes][lane][8] x 2 B
+void pack_pmi_l1(const float *abi_blob, uint16_t *planes, int hidden, float S1);
 // (pairs / scores / n_uav default to the handle's MAAC-R scratch and swarm size; uavtrack_pmi_inference passes its own)
 hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream_t stream, const uint2 *pairs = nullptr,
                             float *scores = nullptr, int n_uav = 0);

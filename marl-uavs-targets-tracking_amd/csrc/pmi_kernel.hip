@@ -60,7 +60,10 @@ struct PmiParams {
     const float *blob;       // folded weights, layout of uavtrack_set_pmi_weights
     const void *x6;          // fc1 as three bf16 planes in MFMA B-operand order (pack_pmi_x6)
     const void *h3;          // fc1 as two f16 planes (hi, lo * 2^11) in MFMA B-operand order (pack_pmi_h3), or null
-    const void *l1;          // the three branch layers as f16 planes in MFMA A-operand order (pack_pmi_l1), with h3
+    const void *l1;          // the three branch layers as f16 planes in MFMA A-operand order (pack_pmi_l1), with t3
+    const void *t3;          // fc1 as two f16 planes of T * w (hi, unscaled remainder) for pmi_score_t3_kernel (pack_pmi_t3), or null
+    float t3_scale;          // S1 * T: the power-of-two scale the t3 kernel's layer-2 accumulators carry (b1 goes in times this)
+    float t3_inv_scale;      // ... and its reciprocal (folded into w2)
     const float *obs;        // [S][B][N][12] local states of the chunk's steps
     const uint2 *pairs;      // {flat [step][b][i] index of i within the chunk, j}
     const unsigned *pair_count;
@@ -264,6 +267,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 // Workgroup barrier that orders LDS traffic only (outstanding global loads stay in flight; the compiler still waits for
 // them where their registers are first used).
+#ifndef UAVTRACK_T3_KO   // timing experiments on pmi_score_t3_kernel only (results are wrong): bit 0 no tile barrier, 1 no producer
+#define UAVTRACK_T3_KO 0  // items, 2 no epilogue items, 3 no B-fragment reads past the first, 4 no layer-2 MFMAs
+#endif
 #define UAVTRACK_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // compile-time loop: f(std::integral_constant<int, 0>) ... f(<N - 1>).  (The staged main loop below indexes register
@@ -617,6 +623,22 @@ __device__ __forceinline__ f2 unpk_f16(unsigned w)
     return f2{(float)h.x, (float)h.y};
 }
 __device__ __forceinline__ f2 scale2(f2 v, float k) { return f2{v.x * k, v.y * k}; }
+// ReLU of both halves of a packed f16 word, one instruction
+__device__ __forceinline__ unsigned relu_h2(unsigned w)
+{
+    unsigned r;
+    asm("v_pk_max_f16 %0, %1, 0" : "=v"(r) : "v"(w));
+    return r;
+}
+// f16 pair of the exact remainders (a0 - hi.lo, a1 - hi.hi): a mixed-precision FMA per value (f16 operand * -1 + fp32 operand,
+// rounded once to f16) -- no unpack, no subtract, no pack
+__device__ __forceinline__ unsigned rem_h2(unsigned hi, float a0, float a1)
+{
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi), "v"(a0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(hi), "v"(a1));
+    return r;
+}
 
 template <int H>
 __global__ void __launch_bounds__(H * 2, 1) pmi_score_h3_kernel(const PmiParams q)
@@ -885,8 +907,19 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_h3_kernel(const PmiParams 
 //     activations as B: the very LDS addresses the A fragments came from), which leaves H2^T in the accumulators: fc2
 //     (PMINet.py:61) is then 16 FMAs down the lane's registers, no cross-lane reduction at all -- the two halves of a
 //     wavefront and the column blocks are added by the thread that stores the score, as before.
-// Accuracy and range: pmi_score_h3_kernel's (same split, same two accumulators per tile; layer 1 now also rounds through
-// an fp32 MFMA accumulation of 13 terms instead of an fmaf chain -- both within 2^-22 relative of the exact sum).
+// The instructions BESIDE the MFMAs set this kernel's time (one wavefront per SIMD: an MFMA gap hides ~5 of them,
+// tools/microbench/mfma_fillers.hip; every further one costs its 4 cycles), and most of them were the operand split of
+// the activations: combine two accumulators, ReLU, pack, unpack, subtract, scale, pack = 6 per value.  Block scaling
+// removes the multiplications: the host folds a power of two S1 into the branch layers and T into fc1 (both exact)
+// such that S1 * activation bound and T * max |w| sit just inside f16's range; a value of that size has a remainder
+// x - f16(x) that is a NORMAL f16 number as it stands (what the 2^11 factor of the h3 kernel was for), for every value
+// above 2^-18 of the bound -- smaller ones lose remainder bits, an absolute error below 2^-25 of the bound's scale, far
+// under the fp32 rounding of the sums they enter (emulated in numpy against fp64: tests/test_host_cpu.py).  Then
+//   hi = f16(acc) (toward zero), ReLU on the packed pair, lo = f16(acc - hi) by ONE mixed-precision FMA per value
+//   (v_fma_mixlo/hi_f16: f16 operand, fp32 operand, f16 result), ReLU on the packed pair        = 2.5 per value;
+// layer 1 accumulates its three products in one accumulator (a third plane, hi * 2^-11, pairs with the 2^11-scaled
+// remainder of the inputs, whose magnitudes have no useful bound from below), layer 2 keeps two accumulators of equal
+// scale S1 T; b1 enters as S1 T b1 and w2 as w2 / (S1 T).  Range: uavtrack_set_pmi_weights (bf16 x 6 kernel otherwise).
 template <int H>
 __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams q)
 {
@@ -916,7 +949,7 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
     const float b2 = w2[H];
     u32x4 Ah[KS], Al[KS];                 // layer 2: W1^T fragments (pack_pmi_h3's B fragments serve as A of the transposed product)
     {
-        const u32x4 *bp = reinterpret_cast<const u32x4 *>(q.h3) + (size_t)w * NP * KS * 64 + lane;
+        const u32x4 *bp = reinterpret_cast<const u32x4 *>(q.t3) + (size_t)w * NP * KS * 64 + lane;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             Ah[s] = bp[(0 * KS + s) * 64];
@@ -925,19 +958,21 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
 #pragma unroll
         for (int s = 0; s < KS; ++s) { asm volatile("" : "+a"(Ah[s])); asm volatile("" : "+a"(Al[s])); }
     }
-    u32x4 L1h[3], L1l[3];                 // layer 1: this wavefront's block of 32 units of each branch (pack_pmi_l1)
+    // layer 1: this wavefront's block of 32 units of each branch (pack_pmi_l1): S1 * w as hi, unscaled remainder, hi * 2^-11
+    constexpr int NP1 = 3;
+    u32x4 L1h[3], L1l[3], L1s[3];
     {
-        const u32x4 *lp = reinterpret_cast<const u32x4 *>(q.l1) + (size_t)w * 3 * NP * 64 + lane;
+        const u32x4 *lp = reinterpret_cast<const u32x4 *>(q.l1) + (size_t)w * 3 * NP1 * 64 + lane;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { L1h[j] = lp[(j * NP + 0) * 64]; L1l[j] = lp[(j * NP + 1) * 64]; }
+        for (int j = 0; j < 3; ++j) { L1h[j] = lp[(j * NP1 + 0) * 64]; L1l[j] = lp[(j * NP1 + 1) * 64]; L1s[j] = lp[(j * NP1 + 2) * 64]; }
     }
     // accumulator row r of a lane is column (unit) m(r) = (r & 3) + 8 (r >> 2) + 4 kh of the wavefront's 32
     f32x16 biasv, w2r;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        biasv[r] = b1[m];
-        w2r[r] = w2[m];
+        biasv[r] = b1[m] * q.t3_scale;          // (powers of two: exact)
+        w2r[r] = w2[m] * q.t3_inv_scale;
     }
 
     // where this lane's 4-unit groups of layer-1 block j land in an activation row: byte (j H + 32 w + 4 kh + 8 g) * 2
@@ -981,33 +1016,28 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
     struct Prod {
         float4 xa, xb;                    // the lane's eight inputs
         unsigned xh[4], xl[4];            // ... as f16 pairs: hi plane, lo plane (B operand of layer 1)
-        f32x16 ah[2], al[2];              // accumulators of two blocks in flight (block j uses slot j & 1)
-        f2 t[2];                          // remainder of the group in flight
-        unsigned pk[2];
+        f32x16 ah[2];                     // accumulators of two blocks in flight (block j uses slot j & 1)
+        f2 t[2];                          // remainder of the input pair in flight
+        unsigned pk[2], lo[2];            // the group in flight: hi words, remainder words
     };
     constexpr int NX = 2 + 4 * 5;                         // two loads; per input pair: pack, convert back, subtract, scale, pack
-    constexpr int NPB = 16 + 4 * 10;                      // per block: 16 x (combine, ReLU); per group of four units ten items
+    constexpr int NPB = 4 * 7;                            // per block: per group of four units seven items (12 VALU, 2 stores)
     constexpr int I_M0 = NX, I_M1 = I_M0 + 3, I_P0 = I_M1 + 3, I_M2 = I_P0 + NPB, I_P1 = I_M2 + 3, I_P2 = I_P1 + NPB;
     constexpr int NITEM = I_P2 + NPB;
     auto post_item = [&](Prod &P, auto jc, auto ic, int abuf) {
         constexpr int j = decltype(jc)::value, i = decltype(ic)::value, sl = j & 1;
-        if constexpr (i < 16) {          // order combine + ReLU (bit-pattern max: one instruction on an MFMA result)
-            P.ah[sl][i] = __int_as_float(max(__float_as_int(fmaf(P.al[sl][i], kH3LoInv, P.ah[sl][i])), 0));
-        } else {
-            constexpr int g = (i - 16) / 10, st = (i - 16) % 10;
-            unsigned char *dst = aplanes + abuf * NP * PLANE + obase + 2 * j * H + 16 * g;
-            const f2 v0 = f2{P.ah[sl][4 * g + 0], P.ah[sl][4 * g + 1]}, v1 = f2{P.ah[sl][4 * g + 2], P.ah[sl][4 * g + 3]};
-            if constexpr (st == 0) { P.pk[0] = pk_f16(v0); P.pk[1] = pk_f16(v1); }
-            else if constexpr (st == 1) *reinterpret_cast<uint2 *>(dst) = make_uint2(P.pk[0], P.pk[1]);
-            else if constexpr (st == 2) P.t[0] = unpk_f16(P.pk[0]);
-            else if constexpr (st == 3) P.t[1] = unpk_f16(P.pk[1]);
-            else if constexpr (st == 4) P.t[0] = sub2(v0, P.t[0]);
-            else if constexpr (st == 5) P.t[1] = sub2(v1, P.t[1]);
-            else if constexpr (st == 6) P.t[0] = scale2(P.t[0], kH3LoScale);
-            else if constexpr (st == 7) P.t[1] = scale2(P.t[1], kH3LoScale);
-            else if constexpr (st == 8) { P.pk[0] = pk_f16(P.t[0]); P.pk[1] = pk_f16(P.t[1]); }
-            else *reinterpret_cast<uint2 *>(dst + PLANE) = make_uint2(P.pk[0], P.pk[1]);
-        }
+        constexpr int g = i / 7, st = i % 7;
+        unsigned char *dst = aplanes + abuf * NP * PLANE + obase + 2 * j * H + 16 * g;
+        const float a0 = P.ah[sl][4 * g + 0], a1 = P.ah[sl][4 * g + 1], a2 = P.ah[sl][4 * g + 2], a3 = P.ah[sl][4 * g + 3];
+        // S1 * z of four adjacent units -> ReLU -> hi = f16 (toward zero), lo = f16(value - hi): hi is clamped first, so a
+        // negative value leaves hi = 0 and a negative remainder, which its own clamp removes
+        if constexpr (st == 0) { P.pk[0] = pk_f16(f2{a0, a1}); P.pk[1] = pk_f16(f2{a2, a3}); }
+        else if constexpr (st == 1) { P.pk[0] = relu_h2(P.pk[0]); P.pk[1] = relu_h2(P.pk[1]); }
+        else if constexpr (st == 2) *reinterpret_cast<uint2 *>(dst) = make_uint2(P.pk[0], P.pk[1]);
+        else if constexpr (st == 3) P.lo[0] = rem_h2(P.pk[0], a0, a1);
+        else if constexpr (st == 4) P.lo[1] = rem_h2(P.pk[1], a2, a3);
+        else if constexpr (st == 5) { P.lo[0] = relu_h2(P.lo[0]); P.lo[1] = relu_h2(P.lo[1]); }
+        else *reinterpret_cast<uint2 *>(dst + PLANE) = make_uint2(P.lo[0], P.lo[1]);
     };
     auto mfma_item = [&](Prod &P, auto jc, auto tc) {
         constexpr int j = decltype(jc)::value, t = decltype(tc)::value, sl = j & 1;
@@ -1015,9 +1045,10 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
         f32x16 zero;
 #pragma unroll
         for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
-        if constexpr (t == 0) P.al[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(L1l[j]), as_f16x8(xh), zero, 0, 0, 0);
-        else if constexpr (t == 1) P.al[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(L1h[j]), as_f16x8(xl), P.al[sl], 0, 0, 0);
-        else P.ah[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(L1h[j]), as_f16x8(xh), zero, 0, 0, 0);
+        // S1 (w . x + b) in ONE accumulator, small terms first: wl xh, (wh 2^-11)(xl 2^11), wh xh
+        if constexpr (t == 0) P.ah[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(L1l[j]), as_f16x8(xh), zero, 0, 0, 0);
+        else if constexpr (t == 1) P.ah[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(L1s[j]), as_f16x8(xl), P.ah[sl], 0, 0, 0);
+        else P.ah[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(L1h[j]), as_f16x8(xh), P.ah[sl], 0, 0, 0);
     };
     auto item = [&](Prod &P, auto ic, int xbuf, int abuf) {
         constexpr int I = decltype(ic)::value;
@@ -1074,7 +1105,7 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
     auto epi_item = [&](const f32x16 &ah, const f32x16 &al, float &sum, auto ec, float *pc) {
         constexpr int e = decltype(ec)::value;
         if constexpr (e < 16) {
-            const float v = __int_as_float(max(__float_as_int(fmaf(al[e], kH3LoInv, ah[e])), 0));
+            const float v = __int_as_float(max(__float_as_int(al[e] + ah[e]), 0));     // (both accumulators carry S1 * T; w2r its reciprocal)
             sum = e == 0 ? v * w2r[0] : fmaf(v, w2r[e], sum);
         } else {
             pc[lane] = sum;
@@ -1117,22 +1148,25 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
                 constexpr int t = decltype(tc)::value;
                 constexpr int slot = 3 * s + t, nslot = 3 * KS;
                 constexpr int lo = slot * NITEM / nslot, hi = (slot + 1) * NITEM / nslot;
-                // H2^T += W1^T H1^T, small terms first: lo += Wl Hh, lo += Wh Hl, hi += Wh Hh
+                // S1 T H2^T += (T W1)^T (S1 H1)^T, small terms first: lo += Wl Hh, lo += Wh Hl, hi += Wh Hh
                 const f16x8 a = as_f16x8(t == 0 ? Al[s] : Ah[s]);
                 const f16x8 bq = as_f16x8(t == 1 ? fl : fh);
-                if constexpr (t == 2) acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, acch, 0, 0, 0);
+                if constexpr ((UAVTRACK_T3_KO & 16) != 0) { asm volatile("" : "+v"(acch), "+v"(accl) : "v"(a), "v"(bq)); }
+                else if constexpr (t == 2) acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, acch, 0, 0, 0);
                 else accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, accl, 0, 0, 0);
-                if constexpr (t == 0 && s + 1 < KS) load_b(s + 1, gh, gl);
+                if constexpr (t == 0 && s + 1 < KS && (UAVTRACK_T3_KO & 8) == 0) load_b(s + 1, gh, gl);
+                if constexpr ((UAVTRACK_T3_KO & 2) == 0)
                 static_for<NITEM>([&](auto ic) {
                     if constexpr (decltype(ic)::value >= lo && decltype(ic)::value < hi) item(P, ic, cur ^ 1, cur ^ 1);
                 });
                 constexpr int elo = slot * 17 / nslot, ehi = (slot + 1) * 17 / nslot;
+                if constexpr ((UAVTRACK_T3_KO & 4) == 0)
                 static_for<17>([&](auto ec) {
                     if constexpr (decltype(ec)::value >= elo && decltype(ec)::value < ehi) epi_item(accph, accpl, esum, ec, pcp);
                 });
                 __builtin_amdgcn_sched_barrier(0);
             });
-            fh = gh; fl = gl;
+            if constexpr ((UAVTRACK_T3_KO & 8) == 0) { fh = gh; fl = gl; }
         });
 
         // xs[cur] fed the producer during the previous iteration: free for iteration it + 2
@@ -1142,7 +1176,7 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
             load_rec(tile_of(it + 2 + 2 * NW), rec_n, rec_ok);
         }
         ++it;
-        UAVTRACK_LDS_BARRIER();
+        if constexpr ((UAVTRACK_T3_KO & 1) == 0) UAVTRACK_LDS_BARRIER();
         if (have_prev) final_sum(tile - G, part + (cur ^ 1) * NW * 64);
         accph = acch; accpl = accl;
         have_prev = true;
@@ -1340,6 +1374,27 @@ __global__ void __launch_bounds__(256) pmi_inference_prep_kernel(const float4 *_
     pairs[k] = make_uint2(2u * k, 1u);
 }
 
+// fc1 for pmi_score_t3_kernel: the element order of pack_pmi_h3, the values block-scaled -- plane 0 = f16(T w), plane 1 =
+// f16(T w - plane 0), T a power of two (uavtrack_set_pmi_weights).
+void pack_pmi_t3(const float *abi_blob, uint16_t *planes, int H, float T)
+{
+    const int K = 3 * H, KS = K / 16, NW = H / 32;
+    const float *W1 = abi_blob + (size_t)15 * H;
+    for (int w = 0; w < NW; ++w)
+        for (int s = 0; s < KS; ++s)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const float v = T * W1[(size_t)(16 * s + 8 * (l >> 5) + j) * H + w * 32 + (l & 31)];
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)(v - (float)hi);
+                    uint16_t bh, bl;
+                    memcpy(&bh, &hi, 2);
+                    memcpy(&bl, &lo, 2);
+                    planes[((((size_t)w * 2 + 0) * KS + s) * 64 + l) * 8 + j] = bh;
+                    planes[((((size_t)w * 2 + 1) * KS + s) * 64 + l) * 8 + j] = bl;
+                }
+}
+
 // fc1 as two f16 planes in the B-operand order of v_mfma_f32_32x32x16_f16 (same element order as pack_pmi_x6):
 // plane 0 = f16(w) (round to nearest), plane 1 = f16((w - plane 0) * 2^11).
 void pack_pmi_h3(const float *abi_blob, uint16_t *planes, int H)
@@ -1363,9 +1418,10 @@ void pack_pmi_h3(const float *abi_blob, uint16_t *planes, int H)
 
 // The branch layers (PMINet.py:50-55, BatchNorm folded) for pmi_score_t3_kernel: per wavefront w and branch j the block of
 // 32 units [32 w, 32 w + 32) as the A operand of v_mfma_f32_32x32x16_f16 over the 16 "inputs" x_0..x_11, 1, 0, 0, 0 --
-// row = unit, k = input: the branch's own inputs carry its weights, input 12 its bias, the rest zeros.  Two planes
-// (f16(v), f16((v - plane 0) * 2^11)); lane l holds k = 8 (l >> 5) .. + 7 of row l & 31.
-void pack_pmi_l1(const float *abi_blob, uint16_t *planes, int H)
+// row = unit, k = input: the branch's own inputs carry its weights, input 12 its bias, the rest zeros.  Three planes of
+// the block-scaled value v = S1 w: f16(v), f16(v - plane 0), plane 0 * 2^-11 (the partner of the inputs' 2^11-scaled
+// remainder); lane l holds k = 8 (l >> 5) .. + 7 of row l & 31.
+void pack_pmi_l1(const float *abi_blob, uint16_t *planes, int H, float S1)
 {
     const int NW = H / 32;
     const int k0[3] = {0, 5, 9}, fan[3] = {5, 4, 3};
@@ -1378,13 +1434,17 @@ void pack_pmi_l1(const float *abi_blob, uint16_t *planes, int H)
                     float v = 0.0f;
                     if (k >= k0[j] && k < k0[j] + fan[j]) v = abi_blob[woff[j] + (size_t)(k - k0[j]) * H + unit];
                     else if (k == 12) v = abi_blob[woff[j] + (size_t)fan[j] * H + unit];
+                    v *= S1;
                     const _Float16 hi = (_Float16)v;
-                    const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
-                    uint16_t bh, bl;
+                    const _Float16 lo = (_Float16)(v - (float)hi);
+                    const _Float16 hs = (_Float16)((float)hi * (1.0f / 2048.0f));
+                    uint16_t bh, bl, bs;
                     memcpy(&bh, &hi, 2);
                     memcpy(&bl, &lo, 2);
-                    planes[((((size_t)w * 3 + j) * 2 + 0) * 64 + l) * 8 + jj] = bh;
-                    planes[((((size_t)w * 3 + j) * 2 + 1) * 64 + l) * 8 + jj] = bl;
+                    memcpy(&bs, &hs, 2);
+                    planes[((((size_t)w * 3 + j) * 3 + 0) * 64 + l) * 8 + jj] = bh;
+                    planes[((((size_t)w * 3 + j) * 3 + 1) * 64 + l) * 8 + jj] = bl;
+                    planes[((((size_t)w * 3 + j) * 3 + 2) * 64 + l) * 8 + jj] = bs;
                 }
 }
 
@@ -1402,6 +1462,9 @@ hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream
     q.x6 = env->pmi.x6;
     q.h3 = env->pmi.h3;
     q.l1 = env->pmi.l1;
+    q.t3 = env->pmi.t3;
+    q.t3_scale = env->pmi.t3_s1 * env->pmi.t3_t;
+    q.t3_inv_scale = 1.0f / q.t3_scale;
     q.obs = obs;
     q.pairs = pairs ? pairs : env->pairs;
     q.pair_count = env->pair_count;
@@ -1423,7 +1486,7 @@ hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream
         const char *s = getenv("UAVTRACK_PMI_SCHEME");
         return !s ? 0 : !strcmp(s, "h3") ? 1 : !strcmp(s, "x6") ? 2 : !strcmp(s, "fp32") ? 3 : !strcmp(s, "t3") ? 4 : 0;
     }();
-    if (q.h3 && q.l1 && !force_fp32 && (scheme == 0 || scheme == 4)) {
+    if (q.t3 && q.l1 && !force_fp32 && (scheme == 0 || scheme == 4)) {
         static const int mult64t = [] {
             const char *e = getenv("UAVTRACK_T3_GRID64");
             const int v = e ? atoi(e) : 2;
