@@ -65,7 +65,7 @@ struct PmiParams {
     float t3_scale;          // S1 * T: the power-of-two scale the t3 kernel's layer-2 accumulators carry (b1 goes in times this)
     float t3_inv_scale;      // ... and its reciprocal (folded into w2)
     const float *obs;        // [S][B][N][12] local states of the chunk's steps
-    const uint2 *pairs;      // {flat [step][b][i] index of i within the chunk, j}
+    const uint2 *pairs;      // {flat [step][b][i] index of i within the chunk, that of j} (0xFFFFFFFF: a dummy of the slot pool)
     const unsigned *pair_count;
     float *scores;           // one per pair, in pair-list order
     unsigned long long *pair_total;
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(H * 2, 2) pmi_score_kernel(const PmiParams q)
         x[0] = x[1] = x[2] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tid < 32 && tile < ntiles && pi < npairs) pr = q.pairs[pi];
         if (tid < 32 && tile < ntiles && pi < npairs && pr.x != 0xFFFFFFFFu) {      // (skips the dummies of the rollout kernel's slot pool)
-            const unsigned gi = pr.x, gj = (pr.x / q.N) * q.N + pr.y;
+            const unsigned gi = pr.x, gj = pr.y;
             const float4 *oi = reinterpret_cast<const float4 *>(q.obs + (size_t)gi * 12);
             const float4 *oj = reinterpret_cast<const float4 *>(q.obs + (size_t)gj * 12);
 #pragma unroll
@@ -270,6 +270,12 @@ __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast
 #ifndef UAVTRACK_T3_KO   // timing experiments on pmi_score_t3_kernel only (results are wrong): bit 0 no tile barrier, 1 no producer
 #define UAVTRACK_T3_KO 0  // items, 2 no epilogue items, 3 no B-fragment reads past the first, 4 no layer-2 MFMAs
 #endif
+#ifndef UAVTRACK_T3_STAMPS   // timing experiment: s_memtime stamps inside the tile loop of workgroup 0, printed by launch_pmi_score
+#define UAVTRACK_T3_STAMPS 0
+#endif
+#if UAVTRACK_T3_STAMPS
+__device__ unsigned long long t3_stamps[4][8];
+#endif
 #define UAVTRACK_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // compile-time loop: f(std::integral_constant<int, 0>) ... f(<N - 1>).  (The staged main loop below indexes register
@@ -389,7 +395,7 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
     auto load_obs = [&](uint2 pr, bool ok, float4 (&a)[3], float4 (&b)[3]) {
         a[0] = a[1] = a[2] = b[0] = b[1] = b[2] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok && pr.x != 0xFFFFFFFFu) {     // (tested HERE, where the record is needed anyway: 0xFFFFFFFF = a dummy of the rollout kernel's slot pool)
-            const unsigned gi = pr.x, gj = (pr.x / q.N) * q.N + pr.y;
+            const unsigned gi = pr.x, gj = pr.y;
             const float4 *oi = reinterpret_cast<const float4 *>(q.obs + (size_t)gi * 12);
             const float4 *oj = reinterpret_cast<const float4 *>(q.obs + (size_t)gj * 12);
 #pragma unroll
@@ -723,7 +729,7 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_h3_kernel(const PmiParams 
     auto load_obs = [&](uint2 pr, bool ok, float4 (&a)[3], float4 (&b)[3]) {
         a[0] = a[1] = a[2] = b[0] = b[1] = b[2] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok && pr.x != 0xFFFFFFFFu) {     // (tested HERE, where the record is needed anyway: 0xFFFFFFFF = a dummy of the rollout kernel's slot pool)
-            const unsigned gi = pr.x, gj = (pr.x / q.N) * q.N + pr.y;
+            const unsigned gi = pr.x, gj = pr.y;
             const float4 *oi = reinterpret_cast<const float4 *>(q.obs + (size_t)gi * 12);
             const float4 *oj = reinterpret_cast<const float4 *>(q.obs + (size_t)gj * 12);
 #pragma unroll
@@ -930,16 +936,19 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
     constexpr int NP = 2;                // planes: hi, lo * 2^11
     constexpr int NW = H / 32;           // wavefronts = column blocks of layer 2 = unit blocks per branch of layer 1
     constexpr int XROW = 16;             // floats per row of the x staging buffer: x_0..11, 1, 0, 0, 0
+    constexpr int kDuty0 = 2, kDutyStep = 2;     // the eleven items of the input duty go behind MFMAs 2, 4, .. 22 of the tile
+    constexpr int kFinalSlot = 26;               // ... and the final sum of the tile before last behind this one
 
     __shared__ float4 lds4[(2 * NP * PLANE + (2 * 32 * XROW + 2 * NW * 64) * 4) / 16 + 2];
     static_assert(H != 64 || 2 * sizeof(lds4) <= 160 * 1024, "two H = 64 workgroups no longer share a CU");
+    static_assert(kDuty0 + 10 * kDutyStep < 3 * (3 * H / 16) && kFinalSlot < 3 * (3 * H / 16), "duty slots past the tile's MFMAs");
     unsigned char *aplanes = reinterpret_cast<unsigned char *>(lds4);               // [2 tiles][2 planes][32 pairs][PITCH]
     float *xs = reinterpret_cast<float *>(aplanes + 2 * NP * PLANE);               // [2 tiles][32 pairs][XROW]
     float *part = xs + 2 * 32 * XROW;                                              // [2 tiles][NW][64 lanes]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int w = tid >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // (scalar: the duty / final-sum tests below are wave-uniform branches)
     const int pr32 = lane & 31;          // the pair (column) this lane holds in every accumulator tile
     const int kh = lane >> 5;
 
@@ -965,6 +974,8 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
         const u32x4 *lp = reinterpret_cast<const u32x4 *>(q.l1) + (size_t)w * 3 * NP1 * 64 + lane;
 #pragma unroll
         for (int j = 0; j < 3; ++j) { L1h[j] = lp[(j * NP1 + 0) * 64]; L1l[j] = lp[(j * NP1 + 1) * 64]; L1s[j] = lp[(j * NP1 + 2) * 64]; }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { asm volatile("" : "+a"(L1h[j])); asm volatile("" : "+a"(L1l[j])); asm volatile("" : "+a"(L1s[j])); }
     }
     // accumulator row r of a lane is column (unit) m(r) = (r & 3) + 8 (r >> 2) + 4 kh of the wavefront's 32
     f32x16 biasv, w2r;
@@ -981,33 +992,24 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
     const int xoff = pr32 * XROW + kh * 8;               // this lane's eight inputs of the layer-1 B operand
 
     const unsigned npairs = *q.pair_count;
+    if (npairs == 0) return;             // (uniform over the grid)
     const unsigned ntiles = (npairs + 31) >> 5;
     const unsigned G = gridDim.x;
 
-    auto load_rec = [&](unsigned tile, uint2 &pr, bool &ok) {
-        const unsigned pi = tile * 32 + lane;                  // (lanes 0..31 of the wavefront on duty)
-        ok = lane < 32 && tile < ntiles && pi < npairs;
-        pr = make_uint2(0, 0);
-        if (ok) pr = q.pairs[pi];
+    // ---- the tile inputs.  Both half-wavefronts carry the same 32 pairs (lanes l and l + 32 request the same addresses --
+    // one transaction -- and store the same values) and indices are clamped rather than masked, so this is straight-line
+    // code for all 64 lanes that the main loop can deal into its MFMA gaps without touching EXEC.
+    auto load_rec = [&](unsigned tile) -> uint2 {
+        return q.pairs[min(tile * 32 + (unsigned)pr32, npairs - 1)];      // (past the end: a valid record whose score nobody stores)
     };
-    auto load_obs = [&](uint2 pr, bool ok, float4 (&a)[3], float4 (&b)[3]) {
-        a[0] = a[1] = a[2] = b[0] = b[1] = b[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok && pr.x != 0xFFFFFFFFu) {     // (tested HERE, where the record is needed anyway: 0xFFFFFFFF = a dummy of the rollout kernel's slot pool)
-            const unsigned gi = pr.x, gj = (pr.x / q.N) * q.N + pr.y;
-            const float4 *oi = reinterpret_cast<const float4 *>(q.obs + (size_t)gi * 12);
-            const float4 *oj = reinterpret_cast<const float4 *>(q.obs + (size_t)gj * 12);
-#pragma unroll
-            for (int v = 0; v < 3; ++v) { a[v] = oi[v]; b[v] = oj[v]; }
-        }
+    struct ObsAddr { const float4 *oi, *oj; };
+    auto obs_addr = [&](uint2 pr) -> ObsAddr {
+        const bool dummy = pr.x == 0xFFFFFFFFu;                            // a dummy of the rollout kernel's slot pool: any row will do
+        const unsigned gi = dummy ? 0u : pr.x, gj = dummy ? 0u : pr.y;
+        return ObsAddr{reinterpret_cast<const float4 *>(q.obs + (size_t)gi * 12), reinterpret_cast<const float4 *>(q.obs + (size_t)gj * 12)};
     };
-    auto stash = [&](int buf, const float4 (&a)[3], const float4 (&b)[3]) {       // x = la_i * la_j (uav.py:281), then 1, 0, 0, 0
-        if (lane < 32) {
-            float4 *dst = reinterpret_cast<float4 *>(xs + buf * 32 * XROW + lane * XROW);
-#pragma unroll
-            for (int v = 0; v < 3; ++v) dst[v] = make_float4(a[v].x * b[v].x, a[v].y * b[v].y, a[v].z * b[v].z, a[v].w * b[v].w);
-            dst[3] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
-        }
-    };
+    auto prod4 = [](const float4 &a, const float4 &b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); };   // x = la_i * la_j (uav.py:281)
+    auto xs_row = [&](int buf) { return reinterpret_cast<float4 *>(xs + buf * 32 * XROW + pr32 * XROW); };
 
     // ---- the producer of one tile's activation planes, as a list of items of one or two instructions each that the main
     //      loop deals out behind its MFMAs: X (operand of layer 1 from the staged inputs), M (its nine MFMAs), P (ReLU,
@@ -1079,22 +1081,29 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
     // therefore rotates over the wavefronts -- the inputs of iteration j are staged by wavefront j mod NW, which requested
     // the observations NW iterations and the record 2 NW iterations ahead: every request has NW tile times to arrive.
     uint2 rec_n;
-    bool rec_ok;
     float4 oa[3], ob[3];
     auto tile_of = [&](unsigned j) { return blockIdx.x + j * G; };
     {
+        auto fetch_obs = [&]() {
+            const ObsAddr A = obs_addr(rec_n);
+#pragma unroll
+            for (int v = 0; v < 3; ++v) { oa[v] = A.oi[v]; ob[v] = A.oj[v]; }
+        };
         if (w == 0) {                                      // iterations 0 and 1: staged here, synchronously
-            load_rec(tile_of(0), rec_n, rec_ok);
-            load_obs(rec_n, rec_ok, oa, ob);
-            stash(0, oa, ob);
-            load_rec(tile_of(1), rec_n, rec_ok);
-            load_obs(rec_n, rec_ok, oa, ob);
-            stash(1, oa, ob);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                rec_n = load_rec(tile_of(b));
+                fetch_obs();
+                float4 *dst = xs_row(b);
+#pragma unroll
+                for (int v = 0; v < 3; ++v) dst[v] = prod4(oa[v], ob[v]);
+                dst[3] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);            // input 12 = 1 (the bias rides on it), 13..15 = 0: written once
+            }
         }
         const unsigned j0 = 2u + (unsigned)((w + NW - 2 % NW) % NW);     // this wavefront's first duty: the iteration j0 >= 2 with j0 mod NW == w
-        load_rec(tile_of(j0), rec_n, rec_ok);
-        load_obs(rec_n, rec_ok, oa, ob);
-        load_rec(tile_of(j0 + NW), rec_n, rec_ok);
+        rec_n = load_rec(tile_of(j0));
+        fetch_obs();
+        rec_n = load_rec(tile_of(j0 + NW));
         __syncthreads();
         Prod P0;
         static_for<NITEM>([&](auto ic) { item(P0, ic, 0, 0); });
@@ -1111,24 +1120,26 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
             pc[lane] = sum;
         }
     };
-    const int ft = tid - (NW - 1) * 64;
     auto final_sum = [&](unsigned tile, const float *pc) {      // over the two half-wavefronts of every column block, in order
-        if (ft >= 0 && ft < 32 && tile * 32 + ft < npairs) {
+        if (tile * 32 + pr32 < npairs) {                        // (both halves of the wavefront compute and store the same value)
             float sc = b2;
 #pragma unroll
-            for (int ww = 0; ww < 2 * NW; ++ww) sc += pc[ww * 32 + ft];
-            q.scores[tile * 32 + ft] = sc;
+            for (int ww = 0; ww < 2 * NW; ++ww) sc += pc[ww * 32 + pr32];
+            q.scores[tile * 32 + pr32] = sc;
         }
     };
 
     int cur = 0;
     unsigned it = 0;
-    bool have_prev = false;
-    f32x16 accph, accpl;                     // the previous tile's accumulators: their epilogue runs under this tile's MFMAs
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { accph[r] = 0.0f; accpl[r] = 0.0f; }
-    for (unsigned tile = blockIdx.x; tile < ntiles; tile += G) {
-        f32x16 acch = biasv, accl;
+#if UAVTRACK_T3_STAMPS
+    unsigned long long stsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    // One tile: layer 2 of iteration `it` into (acch, accl) -- 3 KS MFMAs, the "slots" -- and dealt behind them: the producer of
+    // iteration it + 1's planes, fc2 of iteration it - 1 (accph, accpl), on the wavefront whose turn it is (DUTY) the inputs
+    // of iterations it + 2 .. it + 2 + 2 NW, and on the last wavefront the final sum of iteration it - 2.
+    auto tile_body = [&](auto dutyc, f32x16 &acch, f32x16 &accl, const f32x16 &accph, const f32x16 &accpl) {
+        constexpr bool DUTY = decltype(dutyc)::value;
+        acch = biasv;
 #pragma unroll
         for (int r = 0; r < 16; ++r) accl[r] = 0.0f;
         const unsigned char *bfrag = aplanes + cur * NP * PLANE + bfrag0;
@@ -1139,22 +1150,38 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
         Prod P;
         float esum = 0.0f;
         float *pcp = part + (cur ^ 1) * NW * 64 + w * 64;         // the previous tile's partial scores of this wavefront
-        u32x4 fh, fl, gh, gl;                 // this k-step's fragments, the next one's
-        load_b(0, fh, fl);
+#if UAVTRACK_T3_STAMPS
+        unsigned long long st[6];
+        st[0] = __builtin_amdgcn_s_memtime();
+#endif
+        // B fragments of k-step s live in ring slot s % 3 and are requested TWO k-steps (six MFMAs) ahead: a wavefront's LDS
+        // operations complete in order, so a read queues behind the producer's stores of all four wavefronts, and one
+        // k-step of lead (~100 cycles) did not cover that -- every k-step began with a wait
+        u32x4 fh[3], fl[3];
+        load_b(0, fh[0], fl[0]);
+        if constexpr ((UAVTRACK_T3_KO & 8) == 0) load_b(1, fh[1], fl[1]);
+        // while the first fragments travel: the operand of layer 1 (X items; xs[cur ^ 1] was staged two barriers ago)
+        if constexpr ((UAVTRACK_T3_KO & 2) == 0) static_for<NX>([&](auto ic) { item(P, ic, cur ^ 1, cur ^ 1); });
         __builtin_amdgcn_sched_barrier(0);
+#if UAVTRACK_T3_STAMPS
+        st[1] = __builtin_amdgcn_s_memtime();
+#endif
+        float4 dm;                            // duty: the product row in flight
+        ObsAddr dA;
+        float4 *const dxs = xs_row(cur);      // xs[cur] fed the producer during the previous iteration: free for iteration it + 2
         static_for<KS>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             static_for<3>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 constexpr int slot = 3 * s + t, nslot = 3 * KS;
-                constexpr int lo = slot * NITEM / nslot, hi = (slot + 1) * NITEM / nslot;
+                constexpr int lo = NX + slot * (NITEM - NX) / nslot, hi = NX + (slot + 1) * (NITEM - NX) / nslot;
                 // S1 T H2^T += (T W1)^T (S1 H1)^T, small terms first: lo += Wl Hh, lo += Wh Hl, hi += Wh Hh
                 const f16x8 a = as_f16x8(t == 0 ? Al[s] : Ah[s]);
-                const f16x8 bq = as_f16x8(t == 1 ? fl : fh);
-                if constexpr ((UAVTRACK_T3_KO & 16) != 0) { asm volatile("" : "+v"(acch), "+v"(accl) : "v"(a), "v"(bq)); }
-                else if constexpr (t == 2) acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, acch, 0, 0, 0);
+                constexpr int fs = (UAVTRACK_T3_KO & 8) ? 0 : s % 3;
+                const f16x8 bq = as_f16x8(t == 1 ? fl[fs] : fh[fs]);
+                if constexpr (t == 2) acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, acch, 0, 0, 0);
                 else accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, accl, 0, 0, 0);
-                if constexpr (t == 0 && s + 1 < KS && (UAVTRACK_T3_KO & 8) == 0) load_b(s + 1, gh, gl);
+                if constexpr (t == 0 && s + 2 < KS && (UAVTRACK_T3_KO & 8) == 0) load_b(s + 2, fh[(s + 2) % 3], fl[(s + 2) % 3]);
                 if constexpr ((UAVTRACK_T3_KO & 2) == 0)
                 static_for<NITEM>([&](auto ic) {
                     if constexpr (decltype(ic)::value >= lo && decltype(ic)::value < hi) item(P, ic, cur ^ 1, cur ^ 1);
@@ -1164,32 +1191,71 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
                 static_for<17>([&](auto ec) {
                     if constexpr (decltype(ec)::value >= elo && decltype(ec)::value < ehi) epi_item(accph, accpl, esum, ec, pcp);
                 });
+                if constexpr (DUTY && slot >= kDuty0 && (slot - kDuty0) % kDutyStep == 0 && (slot - kDuty0) / kDutyStep < 11) {
+                    constexpr int d = (slot - kDuty0) / kDutyStep;
+                    // x of iteration it + 2 (observations requested NW iterations ago), then the observations of iteration
+                    // it + 2 + NW (record requested NW iterations ago), then the record of iteration it + 2 + 2 NW
+                    if constexpr (d == 0 || d == 2 || d == 4) dm = prod4(oa[d / 2], ob[d / 2]);
+                    else if constexpr (d == 1 || d == 3 || d == 5) dxs[d / 2] = dm;
+                    else if constexpr (d == 6) dA = obs_addr(rec_n);
+                    else if constexpr (d < 10) { oa[d - 7] = dA.oi[d - 7]; ob[d - 7] = dA.oj[d - 7]; }
+                    else rec_n = load_rec(tile_of(it + 2 + 2 * NW));
+                }
+                if constexpr (slot == kFinalSlot) {
+                    if (w == NW - 1 && it >= 2) final_sum(tile_of(it - 2), part + cur * NW * 64);
+                }
+#if UAVTRACK_T3_STAMPS
+                if constexpr (slot == nslot / 3 - 1) st[2] = __builtin_amdgcn_s_memtime();
+                if constexpr (slot == 2 * nslot / 3 - 1) st[3] = __builtin_amdgcn_s_memtime();
+                if constexpr (slot == nslot - 1) st[4] = __builtin_amdgcn_s_memtime();
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             });
-            if constexpr ((UAVTRACK_T3_KO & 8) == 0) { fh = gh; fl = gl; }
         });
-
-        // xs[cur] fed the producer during the previous iteration: free for iteration it + 2
-        if ((it + 2) % NW == (unsigned)w) {
-            stash(cur, oa, ob);                               // x of iteration it + 2 (observations requested NW iterations ago)
-            load_obs(rec_n, rec_ok, oa, ob);                  // it + 2 + NW (record requested NW iterations ago)
-            load_rec(tile_of(it + 2 + 2 * NW), rec_n, rec_ok);
-        }
         ++it;
         if constexpr ((UAVTRACK_T3_KO & 1) == 0) UAVTRACK_LDS_BARRIER();
-        if (have_prev) final_sum(tile - G, part + (cur ^ 1) * NW * 64);
-        accph = acch; accpl = accl;
-        have_prev = true;
+#if UAVTRACK_T3_STAMPS
+        st[5] = __builtin_amdgcn_s_memtime();
+        if (it > 8) {                        // (steady state) accumulated per wavefront: X items, three thirds of the slots, barrier, tiles, duty tiles
+#pragma unroll
+            for (int k = 0; k < 5; ++k) stsum[k] += st[k + 1] - st[k];
+            stsum[5] += 1;
+            if (DUTY) { stsum[6] += st[5] - st[0]; stsum[7] += 1; }
+        }
+#endif
         cur ^= 1;
+    };
+    auto run_tile = [&](f32x16 &acch, f32x16 &accl, const f32x16 &accph, const f32x16 &accpl) {
+        if ((it + 2) % NW == (unsigned)w) tile_body(std::true_type{}, acch, accl, accph, accpl);
+        else tile_body(std::false_type{}, acch, accl, accph, accpl);
+    };
+    // two accumulator sets take turns (the finished tile's fc2 runs under the next tile's MFMAs): no copies between them
+    f32x16 acc0h, acc0l, acc1h, acc1l;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc1h[r] = 0.0f; acc1l[r] = 0.0f; }
+    bool last_in_0 = false;
+    for (unsigned tile = blockIdx.x; tile < ntiles;) {
+        run_tile(acc0h, acc0l, acc1h, acc1l);
+        tile += G;
+        last_in_0 = true;
+        if (tile >= ntiles) break;
+        run_tile(acc1h, acc1l, acc0h, acc0l);
+        tile += G;
+        last_in_0 = false;
     }
-    if (have_prev) {                         // the last tile's epilogue has nothing left to hide behind
+    if (it > 0) {                            // the last tile's epilogue has nothing left to hide behind
+        if (w == NW - 1 && it >= 2) final_sum(tile_of(it - 2), part + cur * NW * 64);
         float esum = 0.0f;
         float *pcp = part + (cur ^ 1) * NW * 64 + w * 64;
-        static_for<17>([&](auto ec) { epi_item(accph, accpl, esum, ec, pcp); });
+        if (last_in_0) static_for<17>([&](auto ec) { epi_item(acc0h, acc0l, esum, ec, pcp); });
+        else static_for<17>([&](auto ec) { epi_item(acc1h, acc1l, esum, ec, pcp); });
         __syncthreads();
-        const unsigned last = blockIdx.x + ((ntiles - 1 - blockIdx.x) / G) * G;
-        final_sum(last, part + (cur ^ 1) * NW * 64);
+        if (w == NW - 1) final_sum(tile_of(it - 1), part + (cur ^ 1) * NW * 64);
     }
+#if UAVTRACK_T3_STAMPS
+    if (blockIdx.x == 0 && lane == 0 && H == 128)
+        for (int k = 0; k < 8; ++k) t3_stamps[w][k] = stsum[k];
+#endif
 }
 
 struct MixParams {
@@ -1371,7 +1437,7 @@ __global__ void __launch_bounds__(256) pmi_inference_prep_kernel(const float4 *_
         obs2[(size_t)k * 6 + v] = x[(size_t)k * 3 + v];
         obs2[(size_t)k * 6 + 3 + v] = one;
     }
-    pairs[k] = make_uint2(2u * k, 1u);
+    pairs[k] = make_uint2(2u * k, 2u * k + 1u);
 }
 
 // fc1 for pmi_score_t3_kernel: the element order of pack_pmi_h3, the values block-scaled -- plane 0 = f16(T w), plane 1 =
@@ -1499,6 +1565,22 @@ hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream
 #undef UAVTRACK_PMI_CASE
         default: return hipErrorInvalidValue;
         }
+#if UAVTRACK_T3_STAMPS
+        {
+            static int printed = 0;
+            if (printed++ % 16 == 15) {
+                unsigned long long h[4][8];
+                (void)hipStreamSynchronize(stream);
+                (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(t3_stamps), sizeof(h));
+                for (int ww = 0; ww < 4; ++ww) {
+                    const double n = (double)h[ww][5];
+                    if (n > 0) printf("t3 stamps wave %d: tiles %.0f  X %.0f  slots %.0f / %.0f / %.0f  barrier %.0f  | duty tiles %.0f: %.0f per tile\n", ww, n,
+                                      h[ww][0] / n, h[ww][1] / n, h[ww][2] / n, h[ww][3] / n, h[ww][4] / n, (double)h[ww][7], h[ww][7] ? (double)h[ww][6] / h[ww][7] : 0.0);
+                }
+                fflush(stdout);
+            }
+        }
+#endif
         return hipGetLastError();
     }
     if (q.h3 && !force_fp32 && (scheme == 0 || scheme == 1)) {

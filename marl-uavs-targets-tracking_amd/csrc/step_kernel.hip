@@ -694,7 +694,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
             while (later) {                      // ascending j
                 const int j = __ffsll((long long)later) - 1;
                 later &= later - 1;
-                *dst++ = make_uint2(pe_tg, (unsigned)j);
+                *dst++ = make_uint2(pe_tg, pe_tg - (unsigned)i + (unsigned)j);       // {flat index of i, flat index of j}
             }
         }
     };
@@ -1088,7 +1088,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
                 while (later) {                      // ascending j
                     const int j = __ffsll((long long)later) - 1;
                     later &= later - 1;
-                    *dst++ = make_uint2(tg_off, (unsigned)j);
+                    *dst++ = make_uint2(tg_off, tg_off - (unsigned)i + (unsigned)j);
                 }
             }
             if (!pend && pool_left < 2 * total && t + 2 < p.T) {   // about to run dry: ask for the next block now, collect it later
@@ -1166,11 +1166,11 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
                         while (later) {                      // ascending j
                             const int j = __ffsll((long long)later) - 1;
                             later &= later - 1;
-                            *dst++ = make_uint2(tg_off, (unsigned)j);
+                            *dst++ = make_uint2(tg_off, tg_off - (unsigned)i + (unsigned)j);
                         }
                     } else {
                         for (int j = i + 1; j < N; ++j)
-                            if (is_neighbour(j)) *dst++ = make_uint2(tg_off, (unsigned)j);
+                            if (is_neighbour(j)) *dst++ = make_uint2(tg_off, tg_off - (unsigned)i + (unsigned)j);
                     }
                 }
             }

@@ -41,6 +41,23 @@ typedef float v2f __attribute__((ext_vector_type(2)));
                               : "+v"(c0), "+v"(c1) : "v"(a), "v"(b), "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4), "v"(s5), "v"(s6), "v"(s7), "v"(k), "v"(w)); \
     else asm volatile(MFMA0 MFMA1 : "+v"(c0), "+v"(c1) : "v"(a), "v"(b), "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4), "v"(s5), "v"(s6), "v"(s7), "v"(k), "v"(w));
 
+#define DEP3(F) asm volatile(MFMA0 F(4) F(5) F(6) F(7) MFMA0 F(8) F(9) F(10) F(11) MFMA1 F(4) F(5) F(6) F(7)  \
+                              : "+v"(c0), "+v"(c1) : "v"(a), "v"(b), "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4), "v"(s5), "v"(s6), "v"(s7), "v"(k), "v"(w));
+#define DEP3N asm volatile(MFMA0 MFMA0 MFMA1 : "+v"(c0), "+v"(c1) : "v"(a), "v"(b), "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4), "v"(s5), "v"(s6), "v"(s7), "v"(k), "v"(w));
+#define ALT3(F) asm volatile(MFMA0 F(4) F(5) F(6) F(7) MFMA1 F(8) F(9) F(10) F(11) MFMA0 F(4) F(5) F(6) F(7) MFMA1 F(8) F(9) F(10) F(11) MFMA0 F(4) F(5) F(6) F(7) MFMA1 F(8) F(9) F(10) F(11) \
+                              : "+v"(c0), "+v"(c1) : "v"(a), "v"(b), "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4), "v"(s5), "v"(s6), "v"(s7), "v"(k), "v"(w));
+// the scorer's k-step: three MFMAs; behind the first two b128 reads (fragments two k-steps ahead, ring of three) and a b64
+// store, behind all of them VALU fillers; the MFMA that consumes a fragment waits for it with a counted lgkmcnt
+#define KSTEP(RD0, RD1, USE, WR)                                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(3)\n v_mfma_f32_32x32x16_f16 %0, %2, " USE ", %0\n"                                       \
+                 "ds_read_b128 " RD0 ", %13\n ds_read_b128 " RD1 ", %13 offset:25088\n" WR                                     \
+                 "v_fma_f32 %4, %4, %12, %12\n v_fma_f32 %5, %5, %12, %12\n"                                                  \
+                 "v_mfma_f32_32x32x16_f16 %0, %2, " USE ", %0\n"                                                               \
+                 "v_fma_f32 %6, %6, %12, %12\n v_fma_f32 %7, %7, %12, %12\n v_fma_f32 %8, %8, %12, %12\n v_fma_f32 %9, %9, %12, %12\n v_fma_f32 %10, %10, %12, %12\n" \
+                 "v_mfma_f32_32x32x16_f16 %1, %2, " USE ", %1\n"                                                               \
+                 "v_fma_f32 %6, %6, %12, %12\n v_fma_f32 %7, %7, %12, %12\n v_fma_f32 %8, %8, %12, %12\n v_fma_f32 %9, %9, %12, %12\n v_fma_f32 %10, %10, %12, %12\n" \
+                 : "+v"(c0), "+v"(c1), "+v"(a), "+v"(b), "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(s6), "+v"(s7)                 \
+                 : "v"(k), "v"(raddr), "v"(waddr), "v"(wdata), "v"(f0), "v"(f1), "v"(f2) : "memory");
 template <int KIND, int NF>
 __global__ void __launch_bounds__(256) bench(float *out, unsigned long long *ticks, int iters)
 {
@@ -52,6 +69,16 @@ __global__ void __launch_bounds__(256) bench(float *out, unsigned long long *tic
     float s0 = 1.0f + tid, s1 = 2.f, s2 = 3.f, s3 = 4.f, s4 = 5.f, s5 = 6.f, s6 = 7.f, s7 = 8.f;
     const float k = 0.999f;
     const unsigned w = 0x3c003c00u;
+    __shared__ float4 ldsbuf[5000];
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    u4 f0 = {0, 0, 0, 0}, f1 = f0, f2 = f0;
+    const u2 wdata = {w, w};
+    const int lane = tid & 63;
+    // the scorer's addressing: fragment rows of 784 B per pair (conflict-free b128 reads); stores 8 B at row * 784 + ...
+    const unsigned raddr = (lane & 31) * 784 + (lane >> 5) * 16;
+    const unsigned waddr = (KIND == 16 ? (lane & 31) * 784 : (lane & 31) * 776) + (lane >> 5) * 8 + (tid >> 6) * 64;   // 784: 2-way store conflict, 776: none
+    if (tid == 0) ldsbuf[0] = make_float4(0, 0, 0, 0);
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
 #define R16(x) x x x x x x x x x x x x x x x x
@@ -66,6 +93,14 @@ __global__ void __launch_bounds__(256) bench(float *out, unsigned long long *tic
         else if (KIND == 8) { R16(GAPS(F_MUL)) }
         else if (KIND == 9) { R16(GAPS(F_AND)) }
         else if (KIND == 10) { R16(GAPS(F_NOP)) }
+        else if (KIND >= 14 && KIND <= 16) {
+#define WRS "ds_write_b64 %14, %15 offset:50432\n"
+            if (KIND == 14) { R16(KSTEP("%16", "%17", "%3", "") KSTEP("%16", "%17", "%3", "")) }
+            else { R16(KSTEP("%16", "%17", "%3", WRS) KSTEP("%16", "%17", "%3", WRS)) }
+        }
+        else if (KIND == 11) { R16(DEP3(F_FMA)) R16(DEP3(F_FMA)) }     // 96 gaps: same accumulator twice in a row, then the other
+        else if (KIND == 12) { R16(DEP3N) R16(DEP3N) }
+        else if (KIND == 13) { R16(ALT3(F_FMA)) }                      // 96 gaps, alternating accumulators
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float acc = 0.f;
@@ -91,7 +126,8 @@ int run(const char *name)
     CHK(hipMemcpy(h.data(), ticks, (size_t)grid * 4 * 8, hipMemcpyDeviceToHost));
     double s = 0; for (auto v : h) s += (double)v;
     // s_memtime counts at 100 MHz; wall time -> ns per gap; cycles at the clock the MFMA-only loop implies (32 cycles per gap)
-    printf("%-28s NF %d: %7.2f ns per gap (wall)  %7.2f memtime ticks per gap\n", name, NF, ms * 1e6 / iters / 32, s / (grid * 4) / iters / 32);
+    const int gaps = KIND >= 11 ? 96 : 32;   // (KIND 14-16: 32 k-steps of three MFMAs)
+    printf("%-28s NF %d: %7.2f ns per gap (wall)  %7.2f memtime ticks per gap\n", name, NF, ms * 1e6 / iters / gaps, s / (grid * 4) / iters / gaps);
     CHK(hipFree(out)); CHK(hipFree(ticks));
     return 0;
 }
@@ -112,6 +148,12 @@ int main()
         ALLNF(8, "v_mul_f32")
         ALLNF(9, "v_and_b32")
         ALLNF(10, "s_nop 0")
+        run<11, 4>("c0 c0 c1 + 4 v_fma_f32");
+        run<12, 0>("c0 c0 c1 bare");
+        run<13, 4>("c0 c1 c0 c1 + 4 v_fma_f32");
+        run<14, 4>("k-step: 2 b128 reads, 12 fma");
+        run<15, 4>("k-step: + b64 store (no conflict)");
+        run<16, 4>("k-step: + b64 store (2-way)");
     }
     return 0;
 }
