@@ -270,6 +270,9 @@ __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast
 #ifndef UAVTRACK_T3_KO   // timing experiments on pmi_score_t3_kernel only (results are wrong): bit 0 no tile barrier, 1 no producer
 #define UAVTRACK_T3_KO 0  // items, 2 no epilogue items, 3 no B-fragment reads past the first, 4 no layer-2 MFMAs
 #endif
+#ifndef UAVTRACK_T3_BARRIER_BACK   // MFMAs of a tile that run behind its barrier (1 .. 8; 0: the per-width default)
+#define UAVTRACK_T3_BARRIER_BACK 0
+#endif
 #ifndef UAVTRACK_T3_STAMPS   // timing experiment: s_memtime stamps inside the tile loop of workgroup 0, printed by launch_pmi_score
 #define UAVTRACK_T3_STAMPS 0
 #endif
@@ -938,10 +941,14 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
     constexpr int XROW = 16;             // floats per row of the x staging buffer: x_0..11, 1, 0, 0, 0
     constexpr int kDuty0 = 2, kDutyStep = 2;     // the eleven items of the input duty go behind MFMAs 2, 4, .. 22 of the tile
     constexpr int kFinalSlot = 26;               // ... and the final sum of the tile before last behind this one
+    // the tile barrier stands behind this many of the tile's MFMAs (see tile_body; H = 64 -- two workgroups per CU cover each other's barrier -- measured best with 4 behind it, 128 indifferent between 2 and 8)
+    constexpr int kBarrierSlot = 3 * (3 * H / 16) - (UAVTRACK_T3_BARRIER_BACK ? UAVTRACK_T3_BARRIER_BACK : (H <= 64 ? 4 : 6));
 
     __shared__ float4 lds4[(2 * NP * PLANE + (2 * 32 * XROW + 2 * NW * 64) * 4) / 16 + 2];
     static_assert(H != 64 || 2 * sizeof(lds4) <= 160 * 1024, "two H = 64 workgroups no longer share a CU");
     static_assert(kDuty0 + 10 * kDutyStep < 3 * (3 * H / 16) && kFinalSlot < 3 * (3 * H / 16), "duty slots past the tile's MFMAs");
+    static_assert(kDuty0 + 10 * kDutyStep < kBarrierSlot && kFinalSlot < kBarrierSlot && kBarrierSlot > 3 * (3 * H / 16 - 3),
+                  "LDS work behind the tile barrier / a fragment request behind it");
     unsigned char *aplanes = reinterpret_cast<unsigned char *>(lds4);               // [2 tiles][2 planes][32 pairs][PITCH]
     float *xs = reinterpret_cast<float *>(aplanes + 2 * NP * PLANE);               // [2 tiles][32 pairs][XROW]
     float *part = xs + 2 * 32 * XROW;                                              // [2 tiles][NW][64 lanes]
@@ -1109,6 +1116,12 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
         static_for<NITEM>([&](auto ic) { item(P0, ic, 0, 0); });
         __syncthreads();
     }
+    u32x4 nfh[2], nfl[2];                    // the B fragments of the coming tile's k-steps 0 and 1
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        nfh[k] = *reinterpret_cast<const u32x4 *>(aplanes + bfrag0 + 0 * PLANE + k * 32);
+        nfl[k] = *reinterpret_cast<const u32x4 *>(aplanes + bfrag0 + 1 * PLANE + k * 32);
+    }
 
     // fc2 (PMINet.py:60-61) of a finished tile: ReLU(H2) . w2 down the lane's 16 rows; 17 items
     auto epi_item = [&](const f32x16 &ah, const f32x16 &al, float &sum, auto ec, float *pc) {
@@ -1139,6 +1152,7 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
     // of iterations it + 2 .. it + 2 + 2 NW, and on the last wavefront the final sum of iteration it - 2.
     auto tile_body = [&](auto dutyc, f32x16 &acch, f32x16 &accl, const f32x16 &accph, const f32x16 &accpl) {
         constexpr bool DUTY = decltype(dutyc)::value;
+        constexpr int nslot = 3 * KS;
         acch = biasv;
 #pragma unroll
         for (int r = 0; r < 16; ++r) accl[r] = 0.0f;
@@ -1154,18 +1168,11 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
         unsigned long long st[6];
         st[0] = __builtin_amdgcn_s_memtime();
 #endif
-        // B fragments of k-step s live in ring slot s % 3 and are requested TWO k-steps (six MFMAs) ahead: a wavefront's LDS
-        // operations complete in order, so a read queues behind the producer's stores of all four wavefronts, and one
-        // k-step of lead (~100 cycles) did not cover that -- every k-step began with a wait
+        // B fragments of k-step s >= 2 live in ring slot s % 3 and are requested TWO k-steps (six MFMAs) ahead: a wavefront's
+        // LDS operations complete in order, so a read queues behind the producer's stores of all four wavefronts, and one
+        // k-step of lead (~100 cycles) did not cover that.  Those of k-steps 0 and 1 (nfh, nfl) were requested right behind
+        // the previous tile's barrier.
         u32x4 fh[3], fl[3];
-        load_b(0, fh[0], fl[0]);
-        if constexpr ((UAVTRACK_T3_KO & 8) == 0) load_b(1, fh[1], fl[1]);
-        // while the first fragments travel: the operand of layer 1 (X items; xs[cur ^ 1] was staged two barriers ago)
-        if constexpr ((UAVTRACK_T3_KO & 2) == 0) static_for<NX>([&](auto ic) { item(P, ic, cur ^ 1, cur ^ 1); });
-        __builtin_amdgcn_sched_barrier(0);
-#if UAVTRACK_T3_STAMPS
-        st[1] = __builtin_amdgcn_s_memtime();
-#endif
         float4 dm;                            // duty: the product row in flight
         ObsAddr dA;
         float4 *const dxs = xs_row(cur);      // xs[cur] fed the producer during the previous iteration: free for iteration it + 2
@@ -1173,24 +1180,26 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
             constexpr int s = decltype(sc)::value;
             static_for<3>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
-                constexpr int slot = 3 * s + t, nslot = 3 * KS;
-                constexpr int lo = NX + slot * (NITEM - NX) / nslot, hi = NX + (slot + 1) * (NITEM - NX) / nslot;
+                constexpr int slot = 3 * s + t;
                 // S1 T H2^T += (T W1)^T (S1 H1)^T, small terms first: lo += Wl Hh, lo += Wh Hl, hi += Wh Hh
                 const f16x8 a = as_f16x8(t == 0 ? Al[s] : Ah[s]);
-                constexpr int fs = (UAVTRACK_T3_KO & 8) ? 0 : s % 3;
-                const f16x8 bq = as_f16x8(t == 1 ? fl[fs] : fh[fs]);
+                const u32x4 bh = s < 2 ? nfh[s < 2 ? s : 0] : fh[s % 3], bl = s < 2 ? nfl[s < 2 ? s : 0] : fl[s % 3];
+                const f16x8 bq = as_f16x8(t == 1 ? bl : bh);
                 if constexpr (t == 2) acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, acch, 0, 0, 0);
                 else accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, accl, 0, 0, 0);
                 if constexpr (t == 0 && s + 2 < KS && (UAVTRACK_T3_KO & 8) == 0) load_b(s + 2, fh[(s + 2) % 3], fl[(s + 2) % 3]);
-                if constexpr ((UAVTRACK_T3_KO & 2) == 0)
-                static_for<NITEM>([&](auto ic) {
-                    if constexpr (decltype(ic)::value >= lo && decltype(ic)::value < hi) item(P, ic, cur ^ 1, cur ^ 1);
-                });
-                constexpr int elo = slot * 17 / nslot, ehi = (slot + 1) * 17 / nslot;
-                if constexpr ((UAVTRACK_T3_KO & 4) == 0)
-                static_for<17>([&](auto ec) {
-                    if constexpr (decltype(ec)::value >= elo && decltype(ec)::value < ehi) epi_item(accph, accpl, esum, ec, pcp);
-                });
+                if constexpr (slot < kBarrierSlot) {           // everything that touches the LDS images sits in front of the barrier
+                    constexpr int lo = slot * NITEM / kBarrierSlot, hi = (slot + 1) * NITEM / kBarrierSlot;
+                    if constexpr ((UAVTRACK_T3_KO & 2) == 0)
+                    static_for<NITEM>([&](auto ic) {
+                        if constexpr (decltype(ic)::value >= lo && decltype(ic)::value < hi) item(P, ic, cur ^ 1, cur ^ 1);
+                    });
+                    constexpr int elo = slot * 17 / kBarrierSlot, ehi = (slot + 1) * 17 / kBarrierSlot;
+                    if constexpr ((UAVTRACK_T3_KO & 4) == 0)
+                    static_for<17>([&](auto ec) {
+                        if constexpr (decltype(ec)::value >= elo && decltype(ec)::value < ehi) epi_item(accph, accpl, esum, ec, pcp);
+                    });
+                }
                 if constexpr (DUTY && slot >= kDuty0 && (slot - kDuty0) % kDutyStep == 0 && (slot - kDuty0) / kDutyStep < 11) {
                     constexpr int d = (slot - kDuty0) / kDutyStep;
                     // x of iteration it + 2 (observations requested NW iterations ago), then the observations of iteration
@@ -1205,18 +1214,33 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
                     if (w == NW - 1 && it >= 2) final_sum(tile_of(it - 2), part + cur * NW * 64);
                 }
 #if UAVTRACK_T3_STAMPS
-                if constexpr (slot == nslot / 3 - 1) st[2] = __builtin_amdgcn_s_memtime();
-                if constexpr (slot == 2 * nslot / 3 - 1) st[3] = __builtin_amdgcn_s_memtime();
-                if constexpr (slot == nslot - 1) st[4] = __builtin_amdgcn_s_memtime();
+                if constexpr (slot == kBarrierSlot / 3 - 1) st[1] = __builtin_amdgcn_s_memtime();
+                if constexpr (slot == 2 * kBarrierSlot / 3 - 1) st[2] = __builtin_amdgcn_s_memtime();
+                if constexpr (slot == kBarrierSlot - 1) st[3] = __builtin_amdgcn_s_memtime();
 #endif
+                if constexpr (slot == kBarrierSlot - 1) {
+                    // THE tile barrier, six MFMAs before the tile's end: every LDS access of the tile has been issued (the
+                    // last fragment request went out at slot nslot - 9) and is complete behind the wait, so the images
+                    // change hands here -- and the next tile's first two fragment pairs travel under the remaining MFMAs
+                    // instead of in front of an idle matrix pipe
+                    if constexpr ((UAVTRACK_T3_KO & 1) == 0) UAVTRACK_LDS_BARRIER();
+#if UAVTRACK_T3_STAMPS
+                    st[4] = __builtin_amdgcn_s_memtime();
+#endif
+                    const unsigned char *nb = aplanes + (cur ^ 1) * NP * PLANE + bfrag0;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        nfh[k] = *reinterpret_cast<const u32x4 *>(nb + 0 * PLANE + k * 32);
+                        nfl[k] = *reinterpret_cast<const u32x4 *>(nb + 1 * PLANE + k * 32);
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
         ++it;
-        if constexpr ((UAVTRACK_T3_KO & 1) == 0) UAVTRACK_LDS_BARRIER();
 #if UAVTRACK_T3_STAMPS
         st[5] = __builtin_amdgcn_s_memtime();
-        if (it > 8) {                        // (steady state) accumulated per wavefront: X items, three thirds of the slots, barrier, tiles, duty tiles
+        if (it > 8) {                        // (steady state) per wavefront: three thirds of the slots before the barrier, the barrier, the MFMAs behind it
 #pragma unroll
             for (int k = 0; k < 5; ++k) stsum[k] += st[k + 1] - st[k];
             stsum[5] += 1;
@@ -1574,7 +1598,7 @@ hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream
                 (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(t3_stamps), sizeof(h));
                 for (int ww = 0; ww < 4; ++ww) {
                     const double n = (double)h[ww][5];
-                    if (n > 0) printf("t3 stamps wave %d: tiles %.0f  X %.0f  slots %.0f / %.0f / %.0f  barrier %.0f  | duty tiles %.0f: %.0f per tile\n", ww, n,
+                    if (n > 0) printf("t3 stamps wave %d: tiles %.0f  slots before the barrier %.0f / %.0f / %.0f  barrier %.0f  behind it %.0f  | duty tiles %.0f: %.0f per tile\n", ww, n,
                                       h[ww][0] / n, h[ww][1] / n, h[ww][2] / n, h[ww][3] / n, h[ww][4] / n, (double)h[ww][7], h[ww][7] ? (double)h[ww][6] / h[ww][7] : 0.0);
                 }
                 fflush(stdout);

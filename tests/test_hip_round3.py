@@ -188,6 +188,42 @@ def test_pmi_scorer_adversarial_cancellation(uavtrack, hidden):
     env.close()
 
 
+@pytest.mark.parametrize("hidden", [128, 64])
+def test_pmi_scorer_block_scales_at_their_extremes(uavtrack, hidden, pmi_state_dict, pmi_state_dict_h64):
+    """pmi_score_t3_kernel folds powers of two into its f16 planes (S1 into the branch layers from the activation bound, T
+    into fc1 from max |w|: uavtrack_set_pmi_weights) so that operand remainders need no scaling on the device.  The
+    reference-initialised network with its layers scaled far up and far down -- S1 and T at both ends of their ranges,
+    activations from ~1e-4 to ~1e4 of the nominal ones, inputs up to the (x / dc)^2 ~ 250 of a UAV far outside the box --
+    against fp64: 1e-5 relative to sum |terms| (floor 1: the plain 1e-5 of north_star where the sums are O(1))."""
+    base = pmi_state_dict if hidden == 128 else pmi_state_dict_h64
+    env = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(n_envs=1, n_uav=2, m_targets=1, cooperative=0.3,
+                                                    reward_mode=uavtrack.RewardMode.PMI))
+    rng = np.random.RandomState(7 + hidden)
+    n = 4096 + 17
+    x = rng.uniform(-1.0, 1.0, (n, 12)).astype(np.float32)
+    x[: n // 8, 9:11] *= rng.uniform(0.0, 16.0, (n // 8, 1)).astype(np.float32) ** 2        # boundary-state products of a far-away UAV
+    x[n // 8: n // 4] *= np.float32(1e-3)                                                    # ... and inputs that are all tiny
+    xd = torch.from_numpy(x).cuda()
+    report = []
+    for label, s_branch, s_fc1 in (("nominal", 1.0, 1.0), ("branches x 2^5", 32.0, 1.0), ("branches x 2^-12", 2.0 ** -12, 1.0),
+                                   ("fc1 x 2^9", 1.0, 512.0), ("fc1 x 2^-14", 1.0, 2.0 ** -14), ("both up", 16.0, 64.0)):
+        sd = {k: np.array(v, dtype=np.float32) for k, v in base.items()}
+        for bn in ("bn_comm", "bn_obs", "bn_boundary_state"):               # the folded branch layer = s_branch x the nominal one
+            sd[bn + ".weight"] *= np.float32(s_branch)
+            sd[bn + ".bias"] *= np.float32(s_branch)
+        sd["fc1.weight"] *= np.float32(s_fc1)
+        env.set_pmi(sd)
+        got = env.pmi_inference(xd).cpu().numpy().astype(np.float64)
+        ref, mag = pmi_forward_fp64(sd, x, want_scale=True)
+        err = np.abs(got - ref)
+        assert np.isfinite(got).all(), label
+        report.append((label, err.max(), (err / np.maximum(mag, 1.0)).max(), mag.max()))
+        assert (err <= 1e-5 * np.maximum(mag, 1.0)).all(), report[-1]
+    if os.environ.get("UAVTRACK_TEST_REPORT"):
+        print(f"[t3 block scales] H={hidden}: " + "; ".join(f"{l}: max err {e:.2e}, / sum|terms| {r:.2e} (sum|terms| <= {m:.3g})" for l, e, r, m in report))
+    env.close()
+
+
 def test_checkpoint_restores_autoreset_episode_counters(uavtrack):
     """get_state() / set_state() carry the per-environment episode numbers that key the Philox counter of the automatic
     reset (uavtrack_get_episodes / uavtrack_set_episodes): a FRESH handle restored from a checkpoint taken mid-run

@@ -396,3 +396,57 @@ def test_x6_split_error_model_on_adversarial_sums():
         assert (e6 <= 1e-5 * np.maximum(mag, 1.0)).all(), (name, e6.max(), mag.max())
         assert e6.max() <= 2.0 * ec.max() + 1e-6 * mag.max(), (name, e6.max(), ec.max())
         assert e3.max() > 8.0 * e6.max(), (name, e3.max(), e6.max())       # why six products, not three
+
+
+def test_t3_block_scaled_f16_split_error_model():
+    """The arithmetic of pmi_score_t3_kernel's 3H x H layer emulated in numpy: operands block-scaled by powers of two (S on
+    the activations from a BOUND that may be far above the values, T on the weights from max |w|), x = f16(x) (toward
+    zero) + f16(x - hi) with NO scaling of the remainder -- it is a normal f16 number for every value within 2^-12 of the
+    bound, subnormal (a few bits short) below -- three exact products per fp32 product, two fp32 accumulators, small terms
+    first.  Against fp64 it is as accurate as an fp32 fmaf chain on well-scaled data, on the adversarial cancellation
+    layer of conftest, on activations 1000 times smaller than typical, and with the bound 2^12 above the largest value."""
+    from conftest import adversarial_pmi_state_dict
+
+    def rtz16(a):
+        h = a.astype(np.float16)
+        over = np.abs(h.astype(np.float32)) > np.abs(a)
+        return np.where(over, np.nextafter(h, np.float16(0)), h)
+
+    def mm(a, b, acc):
+        for k in range(0, a.shape[1], 16):           # one MFMA: exact products, one fp32 rounding of the k-step's sum
+            acc = (acc.astype(np.float64) + a[:, k:k + 16].astype(np.float64) @ b[k:k + 16].astype(np.float64)).astype(np.float32)
+        return acc
+
+    rng = np.random.RandomState(0)
+    K, N, M = 384, 128, 128
+    cases = {"well_scaled": (np.maximum(rng.randn(M, K).astype(np.float32) * 3, 0), (rng.randn(K, N) * 0.1).astype(np.float32)),
+             "tiny_activations": (np.maximum(rng.randn(M, K).astype(np.float32) * 3e-3, 0), (rng.randn(K, N) * 0.1).astype(np.float32))}
+    sd = adversarial_pmi_state_dict(128, seed=1)
+    h = np.repeat(np.abs(rng.randn(M, K // 2)).astype(np.float32) * 2, 2, axis=1)
+    cases["adversarial"] = (h, np.ascontiguousarray(sd["fc1.weight"].T))
+    for name, (x, w) in cases.items():
+        ref = x.astype(np.float64) @ w.astype(np.float64)
+        mag = np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64)
+        chain = np.zeros((M, N), np.float32)
+        for k in range(K):
+            chain = (chain.astype(np.float64) + x[:, k:k + 1].astype(np.float64) * w[k:k + 1].astype(np.float64)).astype(np.float32)
+        ec = np.abs(chain - ref)
+        for slack in (1.0, 64.0, 4096.0):             # the activation bound over the largest activation
+            S = np.float32(2.0 ** np.floor(np.log2(512.0 / (np.abs(x).max() * slack))))
+            T = np.float32(2.0 ** np.floor(np.log2(32000.0 / np.abs(w).max())))
+            xs, ws = x * S, w * T                      # (powers of two: exact)
+            xh = rtz16(xs)
+            xl = (xs - xh.astype(np.float32)).astype(np.float16)
+            wh = ws.astype(np.float16)
+            wl = (ws - wh.astype(np.float32)).astype(np.float16)
+            f = lambda a: a.astype(np.float32)
+            acc_l, acc_h = np.zeros((M, N), np.float32), np.zeros((M, N), np.float32)
+            for k in range(0, K, 16):
+                sl = slice(k, k + 16)
+                acc_l = mm(f(xh[:, sl]), f(wl[sl]), acc_l)
+                acc_l = mm(f(xl[:, sl]), f(wh[sl]), acc_l)
+                acc_h = mm(f(xh[:, sl]), f(wh[sl]), acc_h)
+            got = (acc_h + acc_l) * np.float32(1.0 / (S * T))
+            e = np.abs(got - ref)
+            assert (e <= 1e-5 * np.maximum(mag, 1e-30)).all(), (name, slack, (e / np.maximum(mag, 1e-30)).max())
+            assert e.max() <= 2.0 * ec.max() + 1e-6 * mag.max(), (name, slack, e.max(), ec.max())
