@@ -940,14 +940,12 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
     constexpr int NW = H / 32;           // wavefronts = column blocks of layer 2 = unit blocks per branch of layer 1
     constexpr int XROW = 16;             // floats per row of the x staging buffer: x_0..11, 1, 0, 0, 0
     constexpr int kDuty0 = 2, kDutyStep = 2;     // the eleven items of the input duty go behind MFMAs 2, 4, .. 22 of the tile
-    constexpr int kFinalSlot = 26;               // ... and the final sum of the tile before last behind this one
     // the tile barrier stands behind this many of the tile's MFMAs (see tile_body; H = 64 -- two workgroups per CU cover each other's barrier -- measured best with 4 behind it, 128 indifferent between 2 and 8)
     constexpr int kBarrierSlot = 3 * (3 * H / 16) - (UAVTRACK_T3_BARRIER_BACK ? UAVTRACK_T3_BARRIER_BACK : (H <= 64 ? 4 : 6));
 
     __shared__ float4 lds4[(2 * NP * PLANE + (2 * 32 * XROW + 2 * NW * 64) * 4) / 16 + 2];
     static_assert(H != 64 || 2 * sizeof(lds4) <= 160 * 1024, "two H = 64 workgroups no longer share a CU");
-    static_assert(kDuty0 + 10 * kDutyStep < 3 * (3 * H / 16) && kFinalSlot < 3 * (3 * H / 16), "duty slots past the tile's MFMAs");
-    static_assert(kDuty0 + 10 * kDutyStep < kBarrierSlot && kFinalSlot < kBarrierSlot && kBarrierSlot > 3 * (3 * H / 16 - 3),
+    static_assert(kDuty0 + 10 * kDutyStep < kBarrierSlot && kBarrierSlot > 3 * (3 * H / 16 - 3),
                   "LDS work behind the tile barrier / a fragment request behind it");
     unsigned char *aplanes = reinterpret_cast<unsigned char *>(lds4);               // [2 tiles][2 planes][32 pairs][PITCH]
     float *xs = reinterpret_cast<float *>(aplanes + 2 * NP * PLANE);               // [2 tiles][32 pairs][XROW]
@@ -1149,7 +1147,7 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
 #endif
     // One tile: layer 2 of iteration `it` into (acch, accl) -- 3 KS MFMAs, the "slots" -- and dealt behind them: the producer of
     // iteration it + 1's planes, fc2 of iteration it - 1 (accph, accpl), on the wavefront whose turn it is (DUTY) the inputs
-    // of iterations it + 2 .. it + 2 + 2 NW, and on the last wavefront the final sum of iteration it - 2.
+    // of iterations it + 2 .. it + 2 + 2 NW, and on the last wavefront, behind the barrier, the final sum of iteration it - 1.
     auto tile_body = [&](auto dutyc, f32x16 &acch, f32x16 &accl, const f32x16 &accph, const f32x16 &accpl) {
         constexpr bool DUTY = decltype(dutyc)::value;
         constexpr int nslot = 3 * KS;
@@ -1185,6 +1183,7 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
                 const f16x8 a = as_f16x8(t == 0 ? Al[s] : Ah[s]);
                 const u32x4 bh = s < 2 ? nfh[s < 2 ? s : 0] : fh[s % 3], bl = s < 2 ? nfl[s < 2 ? s : 0] : fl[s % 3];
                 const f16x8 bq = as_f16x8(t == 1 ? bl : bh);
+                if constexpr (t == 0) asm volatile("" :: "v"(bl));      // (one counted wait per k-step, for both fragments, not two)
                 if constexpr (t == 2) acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, acch, 0, 0, 0);
                 else accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, accl, 0, 0, 0);
                 if constexpr (t == 0 && s + 2 < KS && (UAVTRACK_T3_KO & 8) == 0) load_b(s + 2, fh[(s + 2) % 3], fl[(s + 2) % 3]);
@@ -1210,9 +1209,6 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
                     else if constexpr (d < 10) { oa[d - 7] = dA.oi[d - 7]; ob[d - 7] = dA.oj[d - 7]; }
                     else rec_n = load_rec(tile_of(it + 2 + 2 * NW));
                 }
-                if constexpr (slot == kFinalSlot) {
-                    if (w == NW - 1 && it >= 2) final_sum(tile_of(it - 2), part + cur * NW * 64);
-                }
 #if UAVTRACK_T3_STAMPS
                 if constexpr (slot == kBarrierSlot / 3 - 1) st[1] = __builtin_amdgcn_s_memtime();
                 if constexpr (slot == 2 * kBarrierSlot / 3 - 1) st[2] = __builtin_amdgcn_s_memtime();
@@ -1233,6 +1229,10 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
                         nfh[k] = *reinterpret_cast<const u32x4 *>(nb + 0 * PLANE + k * 32);
                         nfl[k] = *reinterpret_cast<const u32x4 *>(nb + 1 * PLANE + k * 32);
                     }
+                    // the previous tile's partial scores are complete behind the barrier: their sum rides in the gaps of the
+                    // remaining MFMAs, which carry nothing else.  (The buffer is next written two tiles on, by wavefronts that
+                    // have passed the next barrier -- which this wavefront reaches after these reads.)
+                    if (w == NW - 1 && it >= 1) final_sum(tile_of(it - 1), part + (cur ^ 1) * NW * 64);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -1268,7 +1268,6 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
         last_in_0 = false;
     }
     if (it > 0) {                            // the last tile's epilogue has nothing left to hide behind
-        if (w == NW - 1 && it >= 2) final_sum(tile_of(it - 2), part + cur * NW * 64);
         float esum = 0.0f;
         float *pcp = part + (cur ^ 1) * NW * 64 + w * 64;
         if (last_in_0) static_for<17>([&](auto ec) { epi_item(acc0h, acc0l, esum, ec, pcp); });
