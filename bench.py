@@ -457,9 +457,9 @@ def pmi_roofline(args, roof, units_per_launch):
             "whole_call_frac": executed / call_s / 1e12 / BF16_MFMA_PEAK_TFLOPS, "mfma_products_per_fp32_product": nprod, **common,
             "peak_note": "f16 / bf16 MFMA dense peak (~2.5 PFLOP/s, MI355X_MICROARCH.md); executed flops = 3 (f16 split) or 6 (bf16 "
                          "split) MFMAs per fp32 product; fp32_equivalent_* restate the same time as plain fp32 work against the "
-                         "157.3 TFLOP/s fp32-MFMA peak.  With three products per fp32 product the kernel is bound by the VALU work "
-                         "beside the MFMAs (branch layers, ReLU, operand split), not by the matrix pipe: a lower fraction of this "
-                         "roof than the six-product kernel reached, in two thirds of its time",
+                         "157.3 TFLOP/s fp32-MFMA peak.  The peak is the nominal one (2.4 GHz): under this kernel the device holds "
+                         "~1.88 GHz (SQ_BUSY_CU_CYCLES / duration, profiles/r03pmi_summary.md), where its matrix pipes are busy "
+                         "~71 % of the cycles (SQ_VALU_MFMA_BUSY_CYCLES)",
         }
     return {
         "bound": "mfma", "kernel": f"pmi_score_kernel<{hp}>", "achieved": tf_scorer, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
