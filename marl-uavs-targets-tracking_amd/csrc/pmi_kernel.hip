@@ -268,10 +268,16 @@ __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast
 // Workgroup barrier that orders LDS traffic only (outstanding global loads stay in flight; the compiler still waits for
 // them where their registers are first used).
 #ifndef UAVTRACK_T3_KO   // timing experiments on pmi_score_t3_kernel only (results are wrong): bit 0 no tile barrier, 1 no producer
-#define UAVTRACK_T3_KO 0  // items, 2 no epilogue items, 3 no B-fragment reads past the first, 4 no layer-2 MFMAs
+#define UAVTRACK_T3_KO 0  // items, 2 no epilogue items, 3 no B-fragment reads past the first, 5 fragment reads issued but not consumed (no waits)
 #endif
 #ifndef UAVTRACK_T3_BARRIER_BACK   // MFMAs of a tile that run behind its barrier (1 .. 8; 0: the per-width default)
 #define UAVTRACK_T3_BARRIER_BACK 0
+#endif
+#ifndef UAVTRACK_T3_RING           // B-fragment ring of pmi_score_t3_kernel: slots, and k-steps a request runs ahead of its use
+#define UAVTRACK_T3_RING 3
+#endif
+#ifndef UAVTRACK_T3_AHEAD
+#define UAVTRACK_T3_AHEAD 2
 #endif
 #ifndef UAVTRACK_T3_STAMPS   // timing experiment: s_memtime stamps inside the tile loop of workgroup 0, printed by launch_pmi_score
 #define UAVTRACK_T3_STAMPS 0
@@ -991,8 +997,12 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
         w2r[r] = w2[m] * q.t3_inv_scale;
     }
 
-    // where this lane's 4-unit groups of layer-1 block j land in an activation row: byte (j H + 32 w + 4 kh + 8 g) * 2
-    const int obase = pr32 * PITCH + 2 * (32 * w + 4 * kh);
+    // where this lane's units of layer-1 block j land in an activation row: byte (j H + 32 w + 16 kh + r) * 2
+    // A lane's 16 units of a block -- accumulator rows r, units (r & 3) + 8 (r >> 2) + 4 kh -- are stored CONTIGUOUSLY, at
+    // k-positions 16 kh + r of the wavefront's 32: two 16-byte stores per plane and block (conflict-free: eight lanes x four
+    // dwords cover the 32 banks at this pitch; the 8-byte stores of unit order were 2-way).  pack_pmi_t3 lays the fc1 rows
+    // out in the same order; the MFMA does not care which unit sits at which k.
+    const int obase = pr32 * PITCH + 2 * (32 * w + 16 * kh);
     const int bfrag0 = pr32 * PITCH + kh * 16;           // B fragments of layer 2: row = pair, 8 consecutive k per half-wave
     const int xoff = pr32 * XROW + kh * 8;               // this lane's eight inputs of the layer-1 B operand
 
@@ -1025,26 +1035,28 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
         unsigned xh[4], xl[4];            // ... as f16 pairs: hi plane, lo plane (B operand of layer 1)
         f32x16 ah[2];                     // accumulators of two blocks in flight (block j uses slot j & 1)
         f2 t[2];                          // remainder of the input pair in flight
-        unsigned pk[2], lo[2];            // the group in flight: hi words, remainder words
+        unsigned pk[4], lo[4];            // the eight values in flight: hi words, remainder words
     };
     constexpr int NX = 2 + 4 * 5;                         // two loads; per input pair: pack, convert back, subtract, scale, pack
-    constexpr int NPB = 4 * 7;                            // per block: per group of four units seven items (12 VALU, 2 stores)
+    constexpr int NPB = 2 * 12;                           // per block: per half of the lane's 16 units twelve items (20 VALU, 2 stores)
     constexpr int I_M0 = NX, I_M1 = I_M0 + 3, I_P0 = I_M1 + 3, I_M2 = I_P0 + NPB, I_P1 = I_M2 + 3, I_P2 = I_P1 + NPB;
     constexpr int NITEM = I_P2 + NPB;
     auto post_item = [&](Prod &P, auto jc, auto ic, int abuf) {
         constexpr int j = decltype(jc)::value, i = decltype(ic)::value, sl = j & 1;
-        constexpr int g = i / 7, st = i % 7;
-        unsigned char *dst = aplanes + abuf * NP * PLANE + obase + 2 * j * H + 16 * g;
-        const float a0 = P.ah[sl][4 * g + 0], a1 = P.ah[sl][4 * g + 1], a2 = P.ah[sl][4 * g + 2], a3 = P.ah[sl][4 * g + 3];
-        // S1 * z of four adjacent units -> ReLU -> hi = f16 (toward zero), lo = f16(value - hi): hi is clamped first, so a
-        // negative value leaves hi = 0 and a negative remainder, which its own clamp removes
-        if constexpr (st == 0) { P.pk[0] = pk_f16(f2{a0, a1}); P.pk[1] = pk_f16(f2{a2, a3}); }
-        else if constexpr (st == 1) { P.pk[0] = relu_h2(P.pk[0]); P.pk[1] = relu_h2(P.pk[1]); }
-        else if constexpr (st == 2) *reinterpret_cast<uint2 *>(dst) = make_uint2(P.pk[0], P.pk[1]);
-        else if constexpr (st == 3) P.lo[0] = rem_h2(P.pk[0], a0, a1);
-        else if constexpr (st == 4) P.lo[1] = rem_h2(P.pk[1], a2, a3);
-        else if constexpr (st == 5) { P.lo[0] = relu_h2(P.lo[0]); P.lo[1] = relu_h2(P.lo[1]); }
-        else *reinterpret_cast<uint2 *>(dst + PLANE) = make_uint2(P.lo[0], P.lo[1]);
+        constexpr int hf = i / 12, st = i % 12;          // half of the lane's 16 units (eight values = one 16-byte store per plane)
+        unsigned char *dst = aplanes + abuf * NP * PLANE + obase + 2 * j * H + 16 * hf;
+        auto a = [&](int k) { return P.ah[sl][8 * hf + k]; };
+        // S1 * z of eight units -> ReLU -> hi = f16 (toward zero), lo = f16(value - hi): hi is clamped first, so a negative
+        // value leaves hi = 0 and a negative remainder, which its own clamp removes
+        if constexpr (st == 0) { P.pk[0] = pk_f16(f2{a(0), a(1)}); P.pk[1] = pk_f16(f2{a(2), a(3)}); }
+        else if constexpr (st == 1) { P.pk[2] = pk_f16(f2{a(4), a(5)}); P.pk[3] = pk_f16(f2{a(6), a(7)}); }
+        else if constexpr (st == 2) { P.pk[0] = relu_h2(P.pk[0]); P.pk[1] = relu_h2(P.pk[1]); }
+        else if constexpr (st == 3) { P.pk[2] = relu_h2(P.pk[2]); P.pk[3] = relu_h2(P.pk[3]); }
+        else if constexpr (st == 4) *reinterpret_cast<uint4 *>(dst) = make_uint4(P.pk[0], P.pk[1], P.pk[2], P.pk[3]);
+        else if constexpr (st >= 5 && st <= 8) P.lo[st - 5] = rem_h2(P.pk[st - 5], a(2 * (st - 5)), a(2 * (st - 5) + 1));
+        else if constexpr (st == 9) { P.lo[0] = relu_h2(P.lo[0]); P.lo[1] = relu_h2(P.lo[1]); }
+        else if constexpr (st == 10) { P.lo[2] = relu_h2(P.lo[2]); P.lo[3] = relu_h2(P.lo[3]); }
+        else *reinterpret_cast<uint4 *>(dst + PLANE) = make_uint4(P.lo[0], P.lo[1], P.lo[2], P.lo[3]);
     };
     auto mfma_item = [&](Prod &P, auto jc, auto tc) {
         constexpr int j = decltype(jc)::value, t = decltype(tc)::value, sl = j & 1;
@@ -1170,7 +1182,9 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
         // LDS operations complete in order, so a read queues behind the producer's stores of all four wavefronts, and one
         // k-step of lead (~100 cycles) did not cover that.  Those of k-steps 0 and 1 (nfh, nfl) were requested right behind
         // the previous tile's barrier.
-        u32x4 fh[3], fl[3];
+        constexpr int RING = UAVTRACK_T3_RING, AHEAD = UAVTRACK_T3_AHEAD;
+        static_assert(AHEAD >= 2 && AHEAD < RING + 1 && AHEAD <= 4, "fragment ring");
+        u32x4 fh[RING], fl[RING];
         float4 dm;                            // duty: the product row in flight
         ObsAddr dA;
         float4 *const dxs = xs_row(cur);      // xs[cur] fed the producer during the previous iteration: free for iteration it + 2
@@ -1181,12 +1195,15 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
                 constexpr int slot = 3 * s + t;
                 // S1 T H2^T += (T W1)^T (S1 H1)^T, small terms first: lo += Wl Hh, lo += Wh Hl, hi += Wh Hh
                 const f16x8 a = as_f16x8(t == 0 ? Al[s] : Ah[s]);
-                const u32x4 bh = s < 2 ? nfh[s < 2 ? s : 0] : fh[s % 3], bl = s < 2 ? nfl[s < 2 ? s : 0] : fl[s % 3];
+                const u32x4 bh = (s < 2 || (UAVTRACK_T3_KO & 32)) ? nfh[s < 2 ? s : 0] : fh[s % RING], bl = (s < 2 || (UAVTRACK_T3_KO & 32)) ? nfl[s < 2 ? s : 0] : fl[s % RING];
                 const f16x8 bq = as_f16x8(t == 1 ? bl : bh);
                 if constexpr (t == 0) asm volatile("" :: "v"(bl));      // (one counted wait per k-step, for both fragments, not two)
                 if constexpr (t == 2) acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, acch, 0, 0, 0);
                 else accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, accl, 0, 0, 0);
-                if constexpr (t == 0 && s + 2 < KS && (UAVTRACK_T3_KO & 8) == 0) load_b(s + 2, fh[(s + 2) % 3], fl[(s + 2) % 3]);
+                // (k-steps 2 .. AHEAD - 1 are requested at the top of the tile, the others AHEAD k-steps before their use)
+                if constexpr (t == 0 && s == 0 && (UAVTRACK_T3_KO & 8) == 0)
+                    static_for<AHEAD - 2>([&](auto kc) { load_b(2 + decltype(kc)::value, fh[(2 + decltype(kc)::value) % RING], fl[(2 + decltype(kc)::value) % RING]); });
+                if constexpr (t == 0 && s + AHEAD < KS && (UAVTRACK_T3_KO & 8) == 0) load_b(s + AHEAD, fh[(s + AHEAD) % RING], fl[(s + AHEAD) % RING]);
                 if constexpr (slot < kBarrierSlot) {           // everything that touches the LDS images sits in front of the barrier
                     constexpr int lo = slot * NITEM / kBarrierSlot, hi = (slot + 1) * NITEM / kBarrierSlot;
                     if constexpr ((UAVTRACK_T3_KO & 2) == 0)
@@ -1237,6 +1254,10 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
+        if constexpr ((UAVTRACK_T3_KO & 32) != 0) {      // (keep the unconsumed fragment reads alive)
+#pragma unroll
+            for (int k = 0; k < RING; ++k) asm volatile("" :: "v"(fh[k]), "v"(fl[k]));
+        }
         ++it;
 #if UAVTRACK_T3_STAMPS
         st[5] = __builtin_amdgcn_s_memtime();
@@ -1473,7 +1494,11 @@ void pack_pmi_t3(const float *abi_blob, uint16_t *planes, int H, float T)
         for (int s = 0; s < KS; ++s)
             for (int l = 0; l < 64; ++l)
                 for (int j = 0; j < 8; ++j) {
-                    const float v = T * W1[(size_t)(16 * s + 8 * (l >> 5) + j) * H + w * 32 + (l & 31)];
+                    // k-position -> fc1 input: inside a block of 32, position q = 16 kh + r holds unit (r & 3) + 8 (r >> 2) + 4 kh,
+                    // the order in which pmi_score_t3_kernel's lanes store their activations
+                    const int kp = 16 * s + 8 * (l >> 5) + j, q = kp & 31, r = q & 15;
+                    const int row = (kp & ~31) + (r & 3) + 8 * (r >> 2) + 4 * (q >> 4);
+                    const float v = T * W1[(size_t)row * H + w * 32 + (l & 31)];
                     const _Float16 hi = (_Float16)v;
                     const _Float16 lo = (_Float16)(v - (float)hi);
                     uint16_t bh, bl;
