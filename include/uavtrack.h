@@ -132,7 +132,7 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
 
 /* Replaces PMINetwork.inference (PMINet.py:64-72: eval mode, no grad) on a batch: x [n][12] (device; row k is what
  * uav.py:281 builds, la_i * la_j) -> scores [n] (device), with the weights of uavtrack_set_pmi_weights and on the very
- * kernels that score the neighbour pairs of a MAAC-R step (bf16 x 6 or fp32 MFMA by width) -- the network alone, for
+ * kernels that score the neighbour pairs of a MAAC-R step (f16 x 3 on block-scaled planes, bf16 x 6 or fp32 MFMA by width and weight range) -- the network alone, for
  * callers that hold pair inputs of their own and for accuracy tests of the scorer.  Stream-ordered; must not run
  * concurrently with a MAAC-R step of the same handle.  (Not counted by uavtrack_pmi_pairs_scored.) */
 int uavtrack_pmi_inference(uavtrack_env *env, const float *x, int64_t n, float *scores, void *stream);

@@ -66,7 +66,7 @@ struct StepParams {
     int32_t *covered;
     uint8_t *done;
     float *ep_sums;
-    uint2 *pairs;            // MAAC-R: neighbour pair list {flat [t][b][i] index of i, j}, i < j
+    uint2 *pairs;            // MAAC-R: neighbour pair list {flat [t][b][i] index of i, that of j}, i < j (0xFFFFFFFF: slot-pool dummy)
     unsigned *pair_count;
     unsigned long long *pair_total;   // accounting: neighbour pairs emitted so far (uavtrack_pmi_pairs_scored)
     // geometry
