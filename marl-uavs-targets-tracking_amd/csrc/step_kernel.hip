@@ -106,10 +106,25 @@ __device__ __forceinline__ v2f splat(float v) { return (v2f){v, v}; }
 #define UAVTRACK_LE_ASM 1
 #endif
 
+#ifndef UAVTRACK_VCONST            // 1: the single-wavefront kernel variants keep the step loop's float constants in VECTOR registers
+#define UAVTRACK_VCONST 2          // (they have hundreds to spare and run out of scalar ones: see rollout_kernel; 1: the sweeps' constants only)
+#endif
+// a wave-uniform value parked in a vector register (opaque to the compiler: it stays there)
+__device__ __forceinline__ float vreg(float x)
+{
+    float v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x));
+    return v;
+}
+template <bool VC = false>
 __device__ __forceinline__ v2f pk_le_mask(v2f d2, v2f neg_scale, float c)
 {
     v2f r;
     const v2f c2 = splat(c);
+    if constexpr (VC) {
+        asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(d2), "v"(neg_scale), "v"(c2));
+        return r;
+    }
     // (clang treats inline asm as convergent in HIP, which blocks partial unrolling of the sweeps: the
     // Makefile builds this file with -fno-convergent-functions; every cross-lane operation here is a
     // builtin that carries its own convergence)
@@ -246,7 +261,7 @@ __device__ __host__ constexpr bool act_bias_shape(int n_spec) { return n_spec > 
 // Pair sweeps of one UAV, fast path: two agents per packed instruction, no per-agent
 // `j != i` test (self terms are subtracted afterwards).  The uav.py:165/179 weight is 1
 // here (see sweep_weighted).
-template <int N_, int M_, bool Z3, bool NB, int PF, bool SYM = false>
+template <int N_, int M_, bool Z3, bool NB, int PF, bool SYM = false, bool VC = false>
 __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, int i,
                                            const float4 *__restrict__ rowNew, const float4 *__restrict__ rowOld,
                                            const float4 *__restrict__ trow, const v2f *__restrict__ tzrow,
@@ -294,7 +309,7 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
         if (Z3) { const v2f dz = tzrow[kp] - zi2; d2 = pk_fma(dz, dz, d2); }
         const v2f dist = {fast_sqrt(d2.x), fast_sqrt(d2.y)};
 #if UAVTRACK_LE_ASM
-        const v2f mm = pk_le_mask(d2, nscale, p.le_dp2);
+        const v2f mm = pk_le_mask<VC>(d2, nscale, p.le_dp2);
 #else
         const v2f mm = {d2.x <= p.dp2 ? 1.0f : 0.0f, d2.y <= p.dp2 ? 1.0f : 0.0f};
 #endif
@@ -304,7 +319,7 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
         ss = pk_fma(mm, (v2f){q1.z, q1.w}, ss);
         cnt += mm;
         trk = pk_fma(mm, dist, trk);                 // sum m d: tracking reward sum m (1 + (dp - d)/dp) = 2 cnt - (sum m d)/dp
-        cov = pk_fma(cov, splat(4.0f), pk_le_mask(d2, nscale, p.lt_dp2));
+        cov = pk_fma(cov, splat(4.0f), pk_le_mask<VC>(d2, nscale, p.lt_dp2));
         if (kp % kCovPairs == kCovPairs - 1 || kp == MP - 1) {       // 12 digits < 2^24: exact in fp32
             const unsigned bits = (unsigned)cov.x | ((unsigned)cov.y << 1);
             if (bits && !UAVTRACK_KNOCKOUT_COVERAGE) atomicOr(&covw[covbase + kp / kCovPairs], bits);
@@ -346,15 +361,15 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
             }
         }
         if (NBF)       // <= 12 pairs: the same packed mask + base-4 digits as the coverage bits (bit order fixed up below)
-            nbf = pk_fma(nbf, splat(4.0f), pk_le_mask(d2n, nscale, p.le_dp2));
+            nbf = pk_fma(nbf, splat(4.0f), pk_le_mask<VC>(d2n, nscale, p.le_dp2));
         else if (NB)   // cooperative modes (N <= 64): neighbours (d <= dp on post-move poses, uav.py:278) as a bit mask
             nbmask |= ((unsigned long long)(d2n.x <= p.dp2 ? 1u : 0u) | (unsigned long long)(d2n.y <= p.dp2 ? 2u : 0u)) << (2 * jp);
 #if UAVTRACK_LE_ASM
         if (!SYM) {   // (SYM: the duplicate term is shared between the two UAVs of a pair, see sym_dup)
             const v2f w = pk_fma((v2f){fast_sqrt(d2n.x), fast_sqrt(d2n.y)}, splat(-p.exp_k1), splat(p.exp_k0));
-            dup = pk_fma(pk_le_mask(d2n, nscale, p.le_two_dp2), (v2f){fast_exp2(w.x), fast_exp2(w.y)}, dup);
+            dup = pk_fma(pk_le_mask<VC>(d2n, nscale, p.le_two_dp2), (v2f){fast_exp2(w.x), fast_exp2(w.y)}, dup);
         }
-        const v2f mm = pk_le_mask(d2m, nscale, p.le_dc2);
+        const v2f mm = pk_le_mask<VC>(d2m, nscale, p.le_dc2);
 #else
         const v2f w = pk_fma((v2f){fast_sqrt(d2n.x), fast_sqrt(d2n.y)}, splat(-p.exp_k1), splat(p.exp_k0));
         dup += (v2f){d2n.x <= p.two_dp2 ? fast_exp2(w.x) : 0.0f, d2n.y <= p.two_dp2 ? fast_exp2(w.y) : 0.0f};
@@ -401,7 +416,7 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
 // not), and the quantisation (2^-22 per term at N = 50) is far below the fp32 rounding of the sum it replaces.  The
 // accumulator array has 2 N entries: lane i adds to entry i + k without wrapping and reads entries i and i + N.
 // Even N: the opposite peer (k = N/2) is evaluated by both ends, each keeping it for itself.
-template <int N_, bool Z3>
+template <int N_, bool Z3, bool VC = false>
 __device__ __forceinline__ unsigned sym_dup(const StepParams &p, int N, int i, const float *__restrict__ sx, const float *__restrict__ sy,
                                             const float *__restrict__ sz, unsigned *__restrict__ dacc, float xi, float yi, float zi)
 {
@@ -422,7 +437,7 @@ __device__ __forceinline__ unsigned sym_dup(const StepParams &p, int N, int i, c
         v2f d2 = pk_fma(dy, dy, dx * dx);
         if (Z3) { const v2f dz = q.z - zi2; d2 = pk_fma(dz, dz, d2); }
         const v2f w = pk_fma((v2f){fast_sqrt(d2.x), fast_sqrt(d2.y)}, splat(-p.exp_k1), splat(p.sym_k0));
-        const v2f g = pk_le_mask(d2, nscale, p.le_two_dp2) * (v2f){fast_exp2(w.x), fast_exp2(w.y)};
+        const v2f g = pk_le_mask<VC>(d2, nscale, p.le_two_dp2) * (v2f){fast_exp2(w.x), fast_exp2(w.y)};
         return make_uint2((unsigned)g.x, (unsigned)g.y);
     };
     // (the poses of the next two peers are requested before the current two are evaluated: the LDS round trip, the
@@ -534,8 +549,27 @@ __device__ __forceinline__ void sweep_weighted(const StepParams &p, int N, int M
 #define UAVTRACK_OCCUPANCY_ATTR
 #endif
 template <int N_, int M_, int MODE, bool Z3, int POLICY, bool ALLOUT = false, bool EXTRAS = false, bool LONE = false>
-__global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout_kernel(const StepParams p)
+__global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout_kernel(const StepParams p_in)
 {
+    // Single-wavefront variants: a step uses ~40 float constants of StepParams beside ~20 pointers and offsets -- more than
+    // the 102 scalar registers hold, so the compiler parks some in lanes of a vector register and fetches them back with a
+    // v_readlane (a VALU instruction and a wait) wherever they are needed.  These variants run one or two wavefronts per
+    // SIMD and use well under half of their vector registers: the constants that only ever feed per-lane arithmetic
+    // move there for good.
+    constexpr bool kVConst = UAVTRACK_VCONST && LONE;
+    StepParams p = p_in;
+    if (kVConst) {
+#define UAVTRACK_V(f) p.f = vreg(p_in.f)
+        UAVTRACK_V(inv_dp); UAVTRACK_V(inv_dc); UAVTRACK_V(dp2); UAVTRACK_V(dc2); UAVTRACK_V(dup_floor); UAVTRACK_V(inv_dup);
+        UAVTRACK_V(vratio); UAVTRACK_V(inv_na_total); UAVTRACK_V(exp_k0); UAVTRACK_V(exp_k1); UAVTRACK_V(x_max); UAVTRACK_V(y_max);
+        UAVTRACK_V(tt_ceil); UAVTRACK_V(inv_tt_ceil); UAVTRACK_V(alpha); UAVTRACK_V(beta); UAVTRACK_V(gamma);
+        UAVTRACK_V(sym_k0); UAVTRACK_V(sym_inv); UAVTRACK_V(act_bias); UAVTRACK_V(inv_act_bias);
+        UAVTRACK_V(le_neg_scale); UAVTRACK_V(le_dp2); UAVTRACK_V(lt_dp2); UAVTRACK_V(le_dc2); UAVTRACK_V(le_two_dp2);
+#if UAVTRACK_VCONST > 1
+        UAVTRACK_V(dtv_u); UAVTRACK_V(dtv_t); UAVTRACK_V(turn_unit); UAVTRACK_V(inv_na); UAVTRACK_V(two_dp2); UAVTRACK_V(dp); UAVTRACK_V(coop);
+#endif
+#undef UAVTRACK_V
+    }
     constexpr bool GREEDY = POLICY == kPolicyGreedy;
     constexpr bool ACTOR = POLICY == kPolicyActor;
     constexpr bool GIVEN = POLICY == kPolicyGiven;
@@ -866,13 +900,13 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
                         nbmask |= (unsigned long long)(d2 <= p.dp2 ? 1u : 0u) << j;
                     }
             } else {
-                sweep_fast<N_, M_, Z3, kMask, LONE ? ((MODE == UAVTRACK_REWARD_PMI || POLICY != kPolicyGiven) ? UAVTRACK_LDS_PREFETCH_PMI : UAVTRACK_LDS_PREFETCH) : 0, kSym>(p, N, M, i, rowNew, rowOld, tenv, tzrow, covw, cbuf + e * CW,
+                sweep_fast<N_, M_, Z3, kMask, LONE ? ((MODE == UAVTRACK_REWARD_PMI || POLICY != kPolicyGiven) ? UAVTRACK_LDS_PREFETCH_PMI : UAVTRACK_LDS_PREFETCH) : 0, kSym, kVConst>(p, N, M, i, rowNew, rowOld, tenv, tzrow, covw, cbuf + e * CW,
                                               x, y, z, c, s, ai, xo, yo, zo, co, so, ao, acc, nbmask);
             }
             if (kSym) {      // every active lane, whichever sweep it took: its partners count on its half of the pairs
                 const float *sp = symbase + e * symstride;
                 unsigned *dq = const_cast<unsigned *>(reinterpret_cast<const unsigned *>(sp + (Z3 ? 3 : 2) * symlen));
-                sym_own = sym_dup<N_, Z3>(p, N, i, sp, sp + symlen, sp + 2 * symlen, dq, x, y, z);
+                sym_own = sym_dup<N_, Z3, kVConst>(p, N, i, sp, sp + symlen, sp + 2 * symlen, dq, x, y, z);
             }
 
             // ---- P3: local state (uav.py:156-190)
