@@ -432,8 +432,16 @@ def pmi_roofline(args, roof, units_per_launch):
     pairs = roof["pmi_pairs"]
     tf_call = pairs * flop_pair / call_s / 1e12
     tf_scorer = pairs * flop_pair / scorer_s / 1e12
+    traffic, traffic_src = None, None
+    try:      # HBM bytes per scorer launch from the committed PMC profile of this launch shape (profiles/r03pmi*)
+        ent = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(
+            f"{args.envs}x{args.n_uav}x{args.m_targets}_T{roof['T']}_pmi{H}_scorer")
+        if ent and args.box == 2000.0 and args.dim == 2:
+            traffic, traffic_src = ent["hbm_bytes_per_launch"], ent.get("source")
+    except Exception:
+        pass
     common = {
-        "traffic": None, "flop_per_pair": flop_pair, "pairs_scored": pairs,
+        "traffic": traffic, "traffic_source": traffic_src, "flop_per_pair": flop_pair, "pairs_scored": pairs,
         "pairs_per_agent_step": pairs / (units_per_launch * roof["launches"]),
         "timing": "library-side HIP events on the launch stream around every scorer launch of the fixed leg "
                   "(uavtrack_set_profiling); whole_call_* divide by the events around the uavtrack_step_many calls instead "

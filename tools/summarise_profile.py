@@ -73,10 +73,10 @@ for k, c in out.items():
                   f"- HBM traffic per launch: {(rb+wb)/1e6:.1f} MB raw / {(2*rb+wb)/1e6:.1f} MB corrected"]
         if avg_ns:
             lines.append(f"- at {avg_ns/1e3:.1f} us per launch: {(2*rb+wb)/avg_ns:.1f} GB/s of HBM traffic (corrected)")
-        if key and "rollout_kernel" in k:
+        if key and ("rollout_kernel" in k or "pmi_score" in k):
             tf = "profiles/traffic.json"
             tr = json.load(open(tf)) if os.path.exists(tf) else {}
-            tr[key] = dict(hbm_bytes_per_launch=2 * rb + wb, fetch_bytes_raw=rb, write_bytes=wb,
+            tr[key + ("_scorer" if "pmi_score" in k else "")] = dict(hbm_bytes_per_launch=2 * rb + wb, fetch_bytes_raw=rb, write_bytes=wb,
                            source=f"profiles/{tag}_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)")
             json.dump(tr, open(tf, "w"), indent=1, sort_keys=True)
     w = c.get("SQ_WAVES")
