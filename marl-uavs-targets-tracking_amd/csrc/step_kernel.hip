@@ -559,7 +559,9 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
 #ifndef UAVTRACK_VCONST_MULTI       // 1: also the 4-wave variants of the planar specialised shapes (168 registers keep their three waves per SIMD)
 #define UAVTRACK_VCONST_MULTI 0
 #endif
-    constexpr bool kVConst = UAVTRACK_VCONST && (LONE || (UAVTRACK_VCONST_MULTI && !Z3 && N_ > 0 && N_ <= 20));
+    // (not with the actor inside: its variant goes from 156 to 190 registers -- two wavefronts per SIMD instead of three -- and
+    //  a 200-step actor rollout from 2.30 to 2.66 ms)
+    constexpr bool kVConst = UAVTRACK_VCONST && POLICY != kPolicyActor && (LONE || (UAVTRACK_VCONST_MULTI && !Z3 && N_ > 0 && N_ <= 20));
     StepParams p = p_in;
     if (kVConst && !LONE) {       // (4-wave variants: only what the pair sweeps use, the registers that three waves per SIMD leave)
 #define UAVTRACK_V(f) p.f = vreg(p_in.f)
