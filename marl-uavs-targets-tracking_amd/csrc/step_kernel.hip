@@ -556,14 +556,17 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
     // v_readlane (a VALU instruction and a wait) wherever they are needed.  These variants run one or two wavefronts per
     // SIMD and use well under half of their vector registers: the constants that only ever feed per-lane arithmetic
     // move there for good.
+#ifndef UAVTRACK_VCONST_ACTOR       // 1: the sweeps' nine constants also in the single-wavefront actor variants (experiment)
+#define UAVTRACK_VCONST_ACTOR 0
+#endif
 #ifndef UAVTRACK_VCONST_MULTI       // 1: also the 4-wave variants of the planar specialised shapes (168 registers keep their three waves per SIMD)
 #define UAVTRACK_VCONST_MULTI 0
 #endif
     // (not with the actor inside: its variant goes from 156 to 190 registers -- two wavefronts per SIMD instead of three -- and
     //  a 200-step actor rollout from 2.30 to 2.66 ms)
-    constexpr bool kVConst = UAVTRACK_VCONST && POLICY != kPolicyActor && (LONE || (UAVTRACK_VCONST_MULTI && !Z3 && N_ > 0 && N_ <= 20));
+    constexpr bool kVConst = UAVTRACK_VCONST && (POLICY != kPolicyActor || UAVTRACK_VCONST_ACTOR) && (LONE || (UAVTRACK_VCONST_MULTI && !Z3 && N_ > 0 && N_ <= 20));
     StepParams p = p_in;
-    if (kVConst && !LONE) {       // (4-wave variants: only what the pair sweeps use, the registers that three waves per SIMD leave)
+    if (kVConst && (!LONE || POLICY == kPolicyActor)) {       // (4-wave variants: only what the pair sweeps use, the registers that three waves per SIMD leave)
 #define UAVTRACK_V(f) p.f = vreg(p_in.f)
         UAVTRACK_V(le_neg_scale); UAVTRACK_V(le_dp2); UAVTRACK_V(lt_dp2); UAVTRACK_V(le_dc2); UAVTRACK_V(le_two_dp2);
         UAVTRACK_V(exp_k0); UAVTRACK_V(exp_k1); UAVTRACK_V(vratio); UAVTRACK_V(inv_dp);
