@@ -268,7 +268,7 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
                                            unsigned *__restrict__ covw, int covbase,
                                            float xi, float yi, float zi, float ci, float si, float ai,
                                            float xo, float yo, float zo, float co, float so, float ao, Acc &a,
-                                           unsigned long long &nbmask)
+                                           unsigned long long &nbmask, const float4 *const *__restrict__ rsel = nullptr)
 {
     const v2f xi2 = splat(xi), yi2 = splat(yi), zi2 = splat(zi);
     const v2f nscale = splat(p.le_neg_scale);
@@ -289,8 +289,11 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
     constexpr bool kPrefetch = PF > 0 && N_ > 0 && M_ > 0 && QN <= 10 && QM <= 5 && !Z3;
     float4 Q0[QM], Q1[QM], PN0[QN], PM0[QN], PM1[QN];
     v2f PM2[QN];
+    // rsel (single-wavefront headline variant, even / odd steps as two copies of the step loop): the selected copy's row
+    // base per pair, computed once per launch -- which copy is post-move alternates with the step, the choice per pair and
+    // lane does not
     auto fetch_row = [&](int jq) {
-        const float4 *rq = (2 * jq < i) ? rowNew : rowOld;
+        const float4 *rq = rsel ? rsel[jq] : ((2 * jq < i) ? rowNew : rowOld);
         PN0[jq] = rowNew[jq * 6]; PM0[jq] = rq[jq * 6]; PM1[jq] = rq[jq * 6 + 1];
         PM2[jq] = *reinterpret_cast<const v2f *>(&rq[jq * 6 + 2]);
     };
@@ -340,7 +343,7 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
     v2f nbf = splat(0.f);
 #pragma unroll UU
     for (int jp = 0; jp < NP; ++jp) {
-        const float4 *rs = (2 * jp < i) ? rowNew : rowOld;   // one select serves pose, heading, action, z
+        const float4 *rs = (rsel && kPrefetch) ? rsel[kPrefetch ? jp : 0] : ((2 * jp < i) ? rowNew : rowOld);   // one select serves pose, heading, action, z
         if (kPrefetch) {
             if (jp + PF < NP) fetch_row(jp + PF);
             __builtin_amdgcn_sched_barrier(0x407);
@@ -746,7 +749,26 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
         }
     };
 
-    for (int t = 0; t < p.T; ++t) {
+#ifndef UAVTRACK_UNROLL_STEPS       // 2: the single-wavefront variants run even and odd steps as two copies of the loop body -- the table
+#define UAVTRACK_UNROLL_STEPS 2    //    copy that is "post-move" alternates, so per copy every per-pair row address is a per-lane constant (1: off)
+#endif
+    // (an inner loop of constant trip count that is unrolled in full, not `#pragma unroll 2` on the step loop: a loop with
+    //  convergent operations in it is not unrolled when that needs a remainder loop)
+    constexpr int kStepsPerIter = (LONE && MODE == UAVTRACK_REWARD_RAW && POLICY == kPolicyGiven && !EXTRAS) ? UAVTRACK_UNROLL_STEPS : 1;
+    constexpr int kSelPairs = (kStepsPerIter == 2 && N_ > 0) ? (N_ + 1) / 2 : 1;
+    const float4 *selA[kSelPairs], *selB[kSelPairs];     // (kStepsPerIter == 2) row bases of the sequential view, post-move copy 0 / 1
+    if (kStepsPerIter == 2) {
+#pragma unroll
+        for (int jq = 0; jq < kSelPairs; ++jq) {
+            selA[jq] = (2 * jq < i) ? uenv : uenv + 3;
+            selB[jq] = (2 * jq < i) ? uenv + 3 : uenv;
+        }
+    }
+    for (int t0 = 0; t0 < p.T; t0 += kStepsPerIter) {
+#pragma unroll
+    for (int tpar = 0; tpar < kStepsPerIter; ++tpar) {
+        const int t = t0 + tpar;
+        if (kStepsPerIter > 1 && t >= p.T) break;
         const unsigned tg_off = (unsigned)t * (unsigned)BN + g32;   // flat [t][b][i] (MAAC-R pair records; < 2^32 by ensure_pmi_scratch)
         const int cbuf = (t & 1) * E * CW;
 
@@ -914,7 +936,8 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
                     }
             } else {
                 sweep_fast<N_, M_, Z3, kMask, LONE ? ((MODE == UAVTRACK_REWARD_PMI || POLICY != kPolicyGiven) ? UAVTRACK_LDS_PREFETCH_PMI : UAVTRACK_LDS_PREFETCH) : 0, kSym, kVConst>(p, N, M, i, rowNew, rowOld, tenv, tzrow, covw, cbuf + e * CW,
-                                              x, y, z, c, s, ai, xo, yo, zo, co, so, ao, acc, nbmask);
+                                              x, y, z, c, s, ai, xo, yo, zo, co, so, ao, acc, nbmask,
+                                              kStepsPerIter == 2 ? (tpar == 0 ? selA : selB) : nullptr);   // (pn == tpar: t0 is even)
             }
             if (kSym) {      // every active lane, whichever sweep it took: its partners count on its half of the pairs
                 const float *sp = symbase + e * symstride;
@@ -1274,6 +1297,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
         pn ^= 1;
         row += BN;
         rowb += (size_t)p.B;
+    }
     }
     if (kPoolEmit) {                         // what the pool and an uncollected block have left
         pool_dummies(pool_base, pool_left);
