@@ -754,7 +754,10 @@ __global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout
 #endif
     // (an inner loop of constant trip count that is unrolled in full, not `#pragma unroll 2` on the step loop: a loop with
     //  convergent operations in it is not unrolled when that needs a remainder loop)
-    constexpr int kStepsPerIter = (LONE && MODE == UAVTRACK_REWARD_RAW && POLICY == kPolicyGiven && !EXTRAS) ? UAVTRACK_UNROLL_STEPS : 1;
+#ifndef UAVTRACK_UNROLL_STEPS_PMI   // ... the MAAC-R single-wavefront variant too (experiment)
+#define UAVTRACK_UNROLL_STEPS_PMI 0
+#endif
+    constexpr int kStepsPerIter = (LONE && (MODE == UAVTRACK_REWARD_RAW || (UAVTRACK_UNROLL_STEPS_PMI && MODE == UAVTRACK_REWARD_PMI)) && POLICY == kPolicyGiven && !EXTRAS) ? UAVTRACK_UNROLL_STEPS : 1;
     constexpr int kSelPairs = (kStepsPerIter == 2 && N_ > 0) ? (N_ + 1) / 2 : 1;
     const float4 *selA[kSelPairs], *selB[kSelPairs];     // (kStepsPerIter == 2) row bases of the sequential view, post-move copy 0 / 1
     if (kStepsPerIter == 2) {
