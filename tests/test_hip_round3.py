@@ -224,6 +224,24 @@ def test_pmi_scorer_block_scales_at_their_extremes(uavtrack, hidden, pmi_state_d
     env.close()
 
 
+@pytest.mark.parametrize("hidden", [128, 64])
+def test_pmi_inference_tiny_batches(uavtrack, hidden, pmi_state_dict, pmi_state_dict_h64):
+    """The scorer's tile loop at its edges: fewer pairs than one 32-pair tile, exactly one, one more, fewer tiles than
+    workgroups (most workgroups then run the prologue only), and the empty batch."""
+    sd = pmi_state_dict if hidden == 128 else pmi_state_dict_h64
+    env = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(n_envs=1, n_uav=2, m_targets=1, cooperative=0.3,
+                                                    reward_mode=uavtrack.RewardMode.PMI))
+    env.set_pmi(sd)
+    rng = np.random.RandomState(hidden)
+    for n in (1, 2, 31, 32, 33, 64, 65, 257, 8191):
+        x = rng.uniform(-1.0, 1.0, (n, 12)).astype(np.float32)
+        got = env.pmi_inference(torch.from_numpy(x).cuda()).cpu().numpy().astype(np.float64)
+        ref = pmi_forward_fp64(sd, x)
+        assert got.shape == (n,) and np.abs(got - ref).max() < 1e-5, (n, np.abs(got - ref).max())
+    assert env.pmi_inference(torch.empty(0, 12, device="cuda")).shape == (0,)
+    env.close()
+
+
 def test_checkpoint_restores_autoreset_episode_counters(uavtrack):
     """get_state() / set_state() carry the per-environment episode numbers that key the Philox counter of the automatic
     reset (uavtrack_get_episodes / uavtrack_set_episodes): a FRESH handle restored from a checkpoint taken mid-run
