@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Long teacher-forced MAAC-R comparison HIP vs oracle (GPU box; run by hand: `python tests/soak_pmi.py`, not collected by
+pytest): the pair scorer (block-scaled f16 x 3 on the matrix cores) + softmax mix against the unfolded fp64 PMINetwork
+over many steps, boxes (sparse and dense neighbourhoods, UAVs outside the box) and both reference widths."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "marl-uavs-targets-tracking_amd"), os.path.join(ROOT, "tests")]
+import torch
+import uavtrack
+from oracle import OracleConfig, OracleEnv, OraclePmi
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def sd_of(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return {k: z[k] for k in z.files if k != "meta"}
+
+
+def run(B, N, M, box, steps, hidden, seed):
+    sd = sd_of("pmi_h128" if hidden == 128 else "pmi_h64")
+    kw = dict(n_envs=B, n_uav=N, m_targets=M, cooperative=0.3, x_max=box, y_max=box)
+    env = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(reward_mode=uavtrack.RewardMode.PMI, **kw))
+    env.set_pmi(sd); env.reset(seed=seed)
+    orc = OracleEnv(OracleConfig(**kw), n_threads=16)
+    orc.pmi = OraclePmi.from_state_dict(sd)
+    rng = np.random.RandomState(seed)
+    worst = 0.0; skipped = 0; total = 0; moved = 0
+    for t in range(steps):
+        st = {k: v.cpu().numpy() for k, v in env.get_state().items()}
+        orc.set_state(st["ux"], st["uy"], st["uh"], st["ua"], st["tx"], st["ty"], st["th"])
+        act = rng.randint(0, 12, size=(B, N)).astype(np.int32)
+        obs, rew, _ = env.step(torch.from_numpy(act))
+        ref = orc.step(act)
+        ok = ref["margin"] > 1e-3
+        skipped += int((~ok).sum()); total += B
+        if ok.any():
+            worst = max(worst, float(np.abs(rew.cpu().numpy() - ref["reward"])[ok].max()))
+            moved += int((np.abs(ref["reward"] - ref["raw"] if "raw" in ref else 0.0) > 1e-3).sum()) if "raw" in ref else 0
+    print(f"B{B} N{N} M{M} box{box} H{hidden} steps{steps}: max|reward - oracle| = {worst:.2e}; knife-edge env-steps set aside {skipped}/{total}; "
+          f"pairs scored {env.pmi_pairs_scored()}", flush=True)
+    assert worst < 1e-5
+    env.close()
+
+
+t0 = time.time()
+run(512, 20, 10, 2000.0, 120, 128, 1)
+run(512, 20, 10, 500.0, 60, 128, 2)       # dense neighbourhoods
+run(256, 20, 10, 150.0, 60, 64, 3)        # everything in range, UAVs leave the box
+run(128, 50, 25, 2000.0, 40, 128, 4)
+run(64, 70, 5, 900.0, 20, 64, 5)          # more than 64 UAVs: multi-word neighbour records
+print(f"soak_pmi ok in {time.time()-t0:.0f} s")
