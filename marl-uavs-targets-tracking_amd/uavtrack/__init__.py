@@ -14,10 +14,10 @@ from .rollout import ActorMLP, BatchedRollout, sample_actions  # noqa: F401
 from .export import (uav_tracks_from_obs, save_uav_positions, save_covered_num, target_tracks,  # noqa: F401
                      save_target_positions, save_rollout)
 from .replay import DeviceReplayBuffer, PrioritizedDeviceReplayBuffer, transitions_from_rollout  # noqa: F401
-from .pmi_data import sample_pmi_pairs, pmi_contrastive_loss, pmi_batches  # noqa: F401
+from .pmi_data import sample_pmi_pairs, pmi_contrastive_loss, pmi_batches, train_pmi_epoch  # noqa: F401
 from . import _lib  # noqa: F401
 
 __all__ = ["EnvConfig", "RewardMode", "BatchedUavEnv", "Environment", "fold_pmi_state_dict",
            "shard_range", "gather_rollout_summary", "gather_rollout_summary_async", "ActorMLP", "BatchedRollout", "sample_actions",
            "DeviceReplayBuffer", "PrioritizedDeviceReplayBuffer", "transitions_from_rollout",
-           "sample_pmi_pairs", "pmi_contrastive_loss", "pmi_batches", "make_pmi_net"]
+           "sample_pmi_pairs", "pmi_contrastive_loss", "pmi_batches", "train_pmi_epoch", "make_pmi_net"]

@@ -9,13 +9,19 @@ that train.operate_epoch-style loops and the MAAC / MAAC-R actors run unchanged:
     env.save_position(dir, i), env.save_covered_num(dir, i)          # train.py:187,287-288
     uav.get_action_by_direction(env.target_list, env.uav_list)       # train.py:350 (C-METHOD, train.run_epoch)
 
-One reference environment is a batch of one on the GPU; every number it returns comes
-from the HIP kernels through the C ABI (uavtrack.BatchedUavEnv).  `n_envs > 1` keeps the
-same call shapes for env 0 while stepping a whole batch with shared actions -- useful
-only for smoke checks; batched training should use BatchedUavEnv directly.
+One reference environment is a batch of one on the GPU; every number `step` returns comes
+from the HIP kernels through the C ABI (uavtrack.BatchedUavEnv).  Batched training should use
+BatchedUavEnv directly.
+
+Identical seeds: the reference draws its reset from Python's global `random` and every target burns one
+unused draw per step (target.py:34).  A batch of one has no use for the device's Philox reset, so this
+adapter draws the reset on the host from the same generator in the same order and consumes the same
+per-step draws: after `random.seed(s)` it starts from the reference's initial state and a caller's own
+`random.randint` actions are the reference's actions, step after step (tests: g1, g6 with no state injection).
 """
 from __future__ import annotations
 
+import math
 import os
 import random
 from typing import List, Optional
@@ -25,6 +31,43 @@ import torch
 
 from .config import EnvConfig, RewardMode
 from .env import BatchedUavEnv
+
+
+def reference_reset_draw(config, n_uav: int, m_targets: int, x_max: float, y_max: float, action_dim: int):
+    """The reference's reset (environment.py:45-107) as far as it touches Python's global `random`: the same calls in the
+    same order -- per UAV `uniform(-pi, pi)` then `randint(0, action_dim - 1)` (environment.py:66-71), per target
+    `uniform(0, x_max)`, `uniform(0, y_max)`, `uniform(-pi, pi)` and TARGET's unused a0 `uniform(-pi/6, pi/6)`
+    (environment.py:76-81) -- and its fixed UAV layout x_i = i x_max / (n + 1), y = y_max / 2 (environment.py:105-107, from
+    the CONFIG's sizes).  fp64 / int arrays: ux uy uh ua tx ty th."""
+    e = config['environment']
+    pi = math.pi
+    n_cfg = int(e['n_uav'])
+    if n_cfg != n_uav:        # the reference would raise IndexError (fewer) or leave UAVs out (more)
+        raise ValueError(f"config['environment']['n_uav'] = {n_cfg} != the environment's {n_uav}")
+    init_x = [x * e['x_max'] / (n_cfg + 1) for x in range(1, n_cfg + 1)]
+    init_y = e['y_max'] / 2
+    uh, ua = [], []
+    for _ in range(n_uav):
+        uh.append(random.uniform(-pi, pi))
+        ua.append(random.randint(0, action_dim - 1))
+    tx, ty, th = [], [], []
+    for _ in range(m_targets):
+        tx.append(random.uniform(0, x_max))
+        ty.append(random.uniform(0, y_max))
+        th.append(random.uniform(-pi, pi))
+        random.uniform(-pi / 6, pi / 6)
+    return dict(ux=np.asarray(init_x, np.float64), uy=np.full(n_uav, init_y, np.float64), uh=np.asarray(uh, np.float64),
+                ua=np.asarray(ua, np.int64), tx=np.asarray(tx, np.float64), ty=np.asarray(ty, np.float64),
+                th=np.asarray(th, np.float64))
+
+
+def reference_step_draws(config, m_targets: int) -> None:
+    """TARGET.update_position draws one `random.uniform(-h_max, h_max)` per target per step and never uses it (target.py:34;
+    the heading update below it is commented out).  Consumed so that the global generator stays in step with a reference
+    run -- it is what a caller's own action draws and train.py's replay sampling read next."""
+    h_max_t = math.pi / float(config["target"]["h_max"])
+    for _ in range(m_targets):
+        random.uniform(-h_max_t, h_max_t)
 
 
 class _UavView:
@@ -120,13 +163,25 @@ class Environment:
 
     # -- reference surface ------------------------------------------------------------
     def reset(self, config):
-        """environment.py:87-107.  Returns None like the reference.  The seed is drawn from
-        Python's `random`, so `random.seed(42)` (args_util.py:18-21) still pins a run."""
+        """environment.py:87-107.  Returns None like the reference.
+
+        Seed-identical with the reference: the initial state is drawn HERE, on the host, from Python's global `random`
+        in the reference's own order (environment.py:54-83: per UAV `uniform(-pi, pi)` then `randint(0, na - 1)`; per target
+        `uniform(0, x_max)`, `uniform(0, y_max)`, `uniform(-pi, pi)` and the unused `uniform(-pi/6, pi/6)` of TARGET's a0)
+        and injected (uavtrack_set_state) -- so `random.seed(42); env.reset(cfg)` gives the reference's poses (rounded to
+        the library's fp32 state) and leaves the generator where the reference leaves it."""
         self._ensure(config, self._mode_for(config, None) if self._cfg is None else self._cfg.resolved_mode())
-        seed = random.getrandbits(63)
-        obs = self._env.reset(seed=seed, episode=self._episode)
+        st0 = reference_reset_draw(config, self.n_uav, self.m_targets, self.x_max, self.y_max, self.action_dim)
+        ua = st0["ua"]
+        self._env.set_state(**st0, step_count=np.zeros(1, np.int32))
         self._episode += 1
-        self._obs = obs[0].double().cpu().numpy()
+        dc = float(self._cfg.dc)
+        # get_states() of a fresh state: empty observation lists -> -1 (uav.py:174,186), then x / dc, y / dc, a / Na (uav.py:154)
+        obs = np.full((self.n_uav, 12), -1.0)
+        obs[:, 9] = st0["ux"] / dc
+        obs[:, 10] = st0["uy"] / dc
+        obs[:, 11] = np.asarray(ua, np.float64) / float(self.action_dim)
+        self._obs = obs
         self._state_cache = None
         self.uav_list = [_UavView(self, i) for i in range(self.n_uav)]
         self.target_list = [_TargetView(self, k) for k in range(self.m_targets)]
@@ -141,7 +196,9 @@ class Environment:
         step = len(self.covered_target_num)
         if self._greedy_cache is None or self._greedy_cache[0] != (self._episode, step):
             if self._greedy_seed is None:
-                self._greedy_seed = random.getrandbits(63)     # pinned by random.seed like everything else
+                # pinned by random.seed like everything else, without consuming a draw (the library's policy draws are
+                # Philox: the global generator stays where the environment's own draws leave it)
+                self._greedy_seed = hash(random.getstate()) & (2 ** 63 - 1)
             acts = self._env.greedy_actions(seed=self._greedy_seed)[0].cpu().numpy()
             self._greedy_cache = ((self._episode, step), acts)
         return int(self._greedy_cache[1][i])
@@ -152,6 +209,7 @@ class Environment:
         if mode == RewardMode.PMI and (id(pmi) != self._pmi_id or not self.covered_target_num):
             self._env.set_pmi(pmi.state_dict())   # weights change between episodes (train.py:262)
             self._pmi_id = id(pmi)
+        reference_step_draws(config, self.m_targets)           # target.py:34
         a = torch.as_tensor(np.asarray(actions, dtype=np.int32).reshape(1, self.n_uav))
         obs, reward, _ = self._env.step(a)
         terms = self._env.info["terms"][:, 0].double().cpu().numpy()

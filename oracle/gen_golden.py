@@ -22,6 +22,9 @@ Scenarios:
       na 9, 1500 x 1100 box, reward normalisation by config n_uav / m_targets != the environment's own): N20 M10 MAAC-G
       and MAAC-R H64, N7 M4 MAAC; 4 seeds x 25 steps each
   greedy  UAV.get_action_by_direction (uav.py:324-369, the C-METHOD baseline): best_angle per UAV on recorded states
+  f3  PMINetwork.train_pmi (PMINet.py:74-100) on a recorded observation history under torch.manual_seed: the mini-batches it
+      really fed to forward() (= its index draw + per-row copy + batch slicing), their outputs and the returned avg_loss
+  f4  Environment.save_position / save_covered_num (environment.py:229-244) of the g1 episode: the three CSV files, as bytes
 """
 import contextlib
 import io
@@ -323,7 +326,63 @@ def gen_nondefault():
     save("g8_nondefault", arrays, meta)
 
 
+def gen_pmi_train():
+    """f3.  PMINetwork.train_pmi (PMINet.py:74-100) draws torch.randint triples from torch's global generator, copies the
+    rows one by one and walks b2_size // batch_size mini-batches.  What it selected is only visible as the arguments of its
+    own forward() calls, so a recorder is put in front of the instance's forward: inputs and outputs of every call."""
+    n_uav, steps, b2, bs = 20, 50, 300, 64
+    ep = run_episode(make_cfg(n_uav, 10, 0), None, steps, seed=42)            # the g2 episode of seed 42
+    train = torch.tensor(ep["obs"].reshape(steps * n_uav, 12), dtype=torch.float32)   # train.py:183-184 order: step-major, then UAV
+    torch.manual_seed(11)
+    pmi = PMINetwork(hidden_dim=64, b2_size=b2)
+    calls = []
+    inner = pmi.forward
+
+    def recorder(x):
+        y = inner(x)
+        calls.append((x.detach().clone().numpy(), y.detach().clone().numpy()))
+        return y
+    pmi.forward = recorder
+    torch.manual_seed(123)                                                    # the seed the test replays
+    avg_loss = pmi.train_pmi({"pmi": {"batch_size": bs}}, train, n_uav)
+    nb = b2 // bs
+    assert len(calls) == 2 * nb
+    save("f3_pmi_train", dict(train_data=train.numpy(),
+                              in_1_2=np.stack([calls[2 * i][0] for i in range(nb)]), in_1_3=np.stack([calls[2 * i + 1][0] for i in range(nb)]),
+                              out_1_2=np.stack([calls[2 * i][1] for i in range(nb)]), out_1_3=np.stack([calls[2 * i + 1][1] for i in range(nb)]),
+                              avg_loss=np.float64(avg_loss)),
+         dict(n_uav=n_uav, steps=steps, b2_size=b2, batch_size=bs, torch_seed=123, hidden=64,
+              source="PMINetwork.train_pmi, PMINet.py:74-100; obs history = the seed-42 episode of g2"))
+
+
+def gen_export():
+    """f4.  The g1 episode (N5 M3, random.seed(42), 200 steps) through the reference's own writers."""
+    import tempfile
+    cfg = make_cfg(5, 3, 0)
+    env = Environment(n_uav=5, m_targets=3, x_max=2000, y_max=2000, na=12)
+    random.seed(42)
+    env.reset(config=cfg)
+    sink = io.StringIO()
+    for t in range(200):
+        a = [random.randint(0, 11) for _ in range(5)]
+        with contextlib.redirect_stdout(sink):
+            env.step(cfg, None, a)
+    with tempfile.TemporaryDirectory() as d:
+        for sub in ("u_xy", "t_xy", "covered_target_num"):
+            os.makedirs(os.path.join(d, sub))
+        env.save_position(d, 7)
+        env.save_covered_num(d, 7)
+        files = {k: np.frombuffer(open(os.path.join(d, k, f"{k}7.csv"), "rb").read(), dtype=np.uint8)
+                 for k in ("u_xy", "t_xy", "covered_target_num")}
+    save("f4_export", files, dict(episode="g1_n5m3_raw (random.seed(42), 200 steps)", epoch_i=7,
+                                  source="Environment.save_position / save_covered_num, environment.py:229-244"))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-f3f4":
+        gen_pmi_train()
+        gen_export()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--only-nondefault":
         gen_nondefault()
         return
@@ -353,6 +412,8 @@ def main():
     gen_greedy()
     gen_h64()       # (nothing above depends on what it does to the global RNGs)
     gen_nondefault()
+    gen_pmi_train()
+    gen_export()
 
 
 if __name__ == "__main__":

@@ -233,6 +233,87 @@ def test_pmi_training_data_path():
     assert len(batches) == 3 and batches[0][0].shape == (16, 12) and torch.equal(batches[1][1], sel[16:32, 1])
 
 
+def test_pmi_training_path_pinned_to_reference_train_pmi():
+    """f3 against the reference itself: tests/golden/f3_pmi_train.npz holds what PMINetwork.train_pmi
+    (PMINet.py:74-100) really fed to forward() -- its torch.randint triples, per-row copy and batch slicing -- under
+    torch.manual_seed(123) on a recorded observation history, the outputs it got and the avg_loss it returned
+    (oracle/gen_golden.py: gen_pmi_train).  Under the same seed sample_pmi_pairs + pmi_batches must produce those very
+    batches, CustomLoss those losses, and train_pmi_epoch on the same initial weights the same training trajectory."""
+    import torch
+    from conftest import load_golden
+    from uavtrack import sample_pmi_pairs, pmi_contrastive_loss, pmi_batches, train_pmi_epoch, make_pmi_net
+    z, meta = load_golden("f3_pmi_train")
+    N, b2, bs = meta["n_uav"], meta["b2_size"], meta["batch_size"]
+    data = torch.from_numpy(z["train_data"])
+    assert data.shape == (meta["steps"] * N, 12)
+    torch.manual_seed(meta["torch_seed"])
+    sel, t_idx, u_idx = sample_pmi_pairs(data, N, b2)
+    batches = list(pmi_batches(sel, bs))
+    assert len(batches) == b2 // bs == z["in_1_2"].shape[0]
+    for k, (x12, x13) in enumerate(batches):
+        np.testing.assert_array_equal(x12.numpy(), z["in_1_2"][k])
+        np.testing.assert_array_equal(x13.numpy(), z["in_1_3"][k])
+    # the [T, N, 12] form of the same history (what a device rollout returns) selects the same rows
+    torch.manual_seed(meta["torch_seed"])
+    sel3, _, _ = sample_pmi_pairs(data.view(meta["steps"], N, 12), N, b2)
+    assert torch.equal(sel3, sel)
+    # CustomLoss on the reference's recorded outputs -> the avg_loss it returned (mean of |loss| over the batches)
+    losses = [float(pmi_contrastive_loss(torch.from_numpy(z["out_1_2"][k]), torch.from_numpy(z["out_1_3"][k])))
+              for k in range(len(batches))]
+    assert abs(np.mean(np.abs(losses)) - float(z["avg_loss"])) < 1e-6
+    # the whole call: same initial weights (PMINetwork's constructor order and init under manual_seed(11)), Adam(1e-3)
+    torch.manual_seed(11)
+    net = make_pmi_net(meta["hidden"])
+    opt = torch.optim.Adam(net.parameters(), lr=0.001)        # PMINet.py:39
+    seen = []
+    hook = net.register_forward_hook(lambda m, i, o: seen.append((i[0].detach().clone(), o.detach().clone())))
+    torch.manual_seed(meta["torch_seed"])
+    avg = train_pmi_epoch(net, opt, data, N, b2, bs)
+    hook.remove()
+    assert abs(avg - float(z["avg_loss"])) < 1e-5
+    assert len(seen) == 2 * len(batches)
+    for k in range(len(batches)):
+        np.testing.assert_array_equal(seen[2 * k][0].numpy(), z["in_1_2"][k])
+        np.testing.assert_allclose(seen[2 * k][1].numpy(), z["out_1_2"][k], rtol=0, atol=2e-5)     # weights after k Adam steps
+        np.testing.assert_allclose(seen[2 * k + 1][1].numpy(), z["out_1_3"][k], rtol=0, atol=2e-5)
+
+
+def _ref_cfg(n, m, x_max=2000, y_max=2000, na=12):
+    return {"environment": {"n_uav": n, "m_targets": m, "x_max": x_max, "y_max": y_max, "na": na},
+            "uav": {"dt": 1, "v_max": 20, "h_max": 6, "dc": 500, "dp": 200, "alpha": 0.6, "beta": 0.2, "gamma": 0.2},
+            "target": {"v_max": 5, "h_max": 6}, "cooperative": 0}
+
+
+def test_reference_reset_and_step_draws_are_seed_identical():
+    """north_star "on identical seeds": the B = 1 adapter draws its reset from Python's global `random` in the reference's
+    order (environment.py:54-83) and burns the reference's M unused draws per step (target.py:34).  Host half of that,
+    against what the reference itself recorded: g6's four reset layouts and g1's initial state EXACTLY (fp64), and g1's 200 x 5
+    `random.randint` actions exactly -- they were drawn between the steps of the reference run, so they only come out
+    right if every step has consumed what the reference's step consumes."""
+    import random
+    from conftest import load_golden
+    from uavtrack.compat import reference_reset_draw, reference_step_draws
+    z6, meta6 = load_golden("g6_reset")
+    for tag, mm in meta6.items():
+        n, m = mm["n_uav"], mm["m_targets"]
+        random.seed(42)
+        st = reference_reset_draw(_ref_cfg(n, m), n, m, 2000, 2000, 12)
+        for k in ("ux", "uy", "uh", "ua", "tx", "ty", "th"):
+            np.testing.assert_array_equal(st[k], z6[f"{tag}_{k}"], err_msg=f"{tag} {k}")
+    z1, meta1 = load_golden("g1_n5m3_raw")
+    cfg = _ref_cfg(5, 3)
+    random.seed(meta1["seeds"][0])
+    st = reference_reset_draw(cfg, 5, 3, 2000, 2000, 12)
+    for k in ("ux", "uy", "uh", "ua", "tx", "ty", "th"):
+        np.testing.assert_array_equal(st[k], z1[k][0, 0], err_msg=k)
+    for t in range(meta1["steps"]):
+        a = [random.randint(0, 11) for _ in range(5)]
+        assert a == [int(v) for v in z1["actions"][0, t]], t
+        reference_step_draws(cfg, 3)
+    with pytest.raises(ValueError):
+        reference_reset_draw(_ref_cfg(6, 3), 5, 3, 2000, 2000, 12)
+
+
 def build_abi_client(tmp_path):
     """gcc (C99, no C++, no Python) against include/uavtrack.h + libuavtrack.so + the HIP runtime."""
     import subprocess
