@@ -130,6 +130,30 @@ int uavtrack_get_episodes(uavtrack_env *env, int32_t *episode, void *stream);
 int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_floats,
                              int32_t hidden, void *stream);
 
+/* Which arithmetic scores the neighbour pairs (the 3H x H layer of PMINet.py:59, 98 % of the network's work).  All
+ * three evaluate PMINetwork.forward at fp32 accuracy (tested against an fp64 forward); they differ in speed and range:
+ *   F16X3   three f16 MFMAs per fp32 product on block-scaled operand planes -- the default for hidden 64 / 96 / 128 when
+ *           the weights and the activation bounds fit f16's range; it watches its inputs, and a chunk in which an operand
+ *           could saturate is scored again by BF16X6 (stream-ordered, counted in uavtrack_pmi_info);
+ *   BF16X6  six bf16 MFMAs per fp32 product: fp32's exponent range -- networks the range guard turns away;
+ *   FP32    fp32-input MFMA: every width up to 256 (the only kernel for 32 and for widths past 128). */
+enum uavtrack_pmi_scheme {
+    UAVTRACK_PMI_AUTO   = 0,    /* the fastest one the weights allow (the default) */
+    UAVTRACK_PMI_F16X3  = 1,
+    UAVTRACK_PMI_BF16X6 = 2,
+    UAVTRACK_PMI_FP32   = 3
+};
+
+/* Pins the scorer (A/B measurements, parity tests of every dispatchable kernel).  Fails when the loaded weights
+ * cannot run on that scheme (width, or f16 range); uavtrack_set_pmi_weights fails likewise while a scheme is pinned. */
+int uavtrack_set_pmi_scheme(uavtrack_env *env, int32_t scheme);
+
+/* out[0] = the scheme the next MAAC-R step / uavtrack_pmi_inference will launch (enum uavtrack_pmi_scheme, never AUTO;
+ * 0 without weights), out[1] = the hidden width after padding to a multiple of 32, out[2] = 1 if the weights passed the
+ * host-side f16 range guard, out[3] = chunks the wide-range kernel has re-scored since the handle was created because an
+ * operand left f16's range at run time.  Synchronises `stream`. */
+int uavtrack_pmi_info(uavtrack_env *env, int64_t out[4], void *stream);
+
 /* Replaces PMINetwork.inference (PMINet.py:64-72: eval mode, no grad) on a batch: x [n][12] (device; row k is what
  * uav.py:281 builds, la_i * la_j) -> scores [n] (device), with the weights of uavtrack_set_pmi_weights and on the very
  * kernels that score the neighbour pairs of a MAAC-R step (f16 x 3 on block-scaled planes, bf16 x 6 or fp32 MFMA by width and weight range) -- the network alone, for
@@ -261,6 +285,12 @@ int uavtrack_get_profile(uavtrack_env *env, double *ms, int64_t *launches, void 
  * out[1] = envs per workgroup, out[2] = workgroups, out[3] = LDS bytes per
  * workgroup, out[4] = 1 if a compile-time-specialised (N, M) variant is used. */
 int uavtrack_kernel_info(uavtrack_env *env, int64_t out[5]);
+
+/* Geometry of the most recent rollout launch of a stepping entry point (MAAC-R picks it per launch: the single-wavefront
+ * variant exists for launches with every output and no extras only): out[0] = workgroup size, out[1] = envs per
+ * workgroup, out[2] = workgroups, out[3] = 1 if the single-wavefront (pooled pair-list slots) kernel variant ran.
+ * All zero before the first launch. */
+int uavtrack_launch_info(uavtrack_env *env, int64_t out[4]);
 
 #ifdef __cplusplus
 }

@@ -84,7 +84,12 @@ hipError_t timed_launch(uavtrack_env *env, int cls, hipStream_t st, F &&launch)
     hipError_t e = hipEventCreate(&r.a);
     if (e == hipSuccess) e = hipEventCreate(&r.b);
     if (e == hipSuccess) e = hipEventRecord(r.a, st);
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess) {          // no events to be had: the step still runs, this launch just goes untimed
+        if (r.a) (void)hipEventDestroy(r.a);
+        if (r.b) (void)hipEventDestroy(r.b);
+        (void)hipGetLastError();
+        return launch();
+    }
     e = launch();
     if (e == hipSuccess) e = hipEventRecord(r.b, st);
     env->prof.push_back(r);
@@ -95,7 +100,7 @@ void free_state(uavtrack_env *env)
 {
     drop_profile(env);
     void *ptrs[] = {env->slab, env->pmi.blob, env->actor_w, env->pairs, env->pair_count, env->pair_total, env->scores, env->nbrec,
-                    env->obs_tmp, env->rsum, env->inf_obs, env->inf_pairs};
+                    env->obs_tmp, env->rsum, env->inf_obs, env->inf_pairs, env->pmi_flags};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -112,9 +117,6 @@ int validate(const uavtrack_config &c)
     if (c.nc < 1 || c.nc > UAVTRACK_MAX_CLIMB) return fail("nc must be in [1, %d] (got %d)", UAVTRACK_MAX_CLIMB, c.nc);
     if (c.dim == 2 && c.nc != 1) return fail("nc must be 1 when dim == 2 (got %d)", c.nc);
     if (c.norm_n_uav < 1 || c.norm_m_targets < 1) return fail("norm_n_uav / norm_m_targets must be >= 1");
-    // swarms of up to 64 UAVs count neighbours in the high part of an exact fp32 integer sum (step_kernel.hip act_bias_shape)
-    if (c.n_uav <= 64 && (int64_t)c.n_uav * c.n_uav * c.na * c.nc * 4 >= ((int64_t)1 << 24))
-        return fail("na * nc = %d actions is beyond what a swarm of %d UAVs supports (n_uav^2 * na * nc must stay below 2^22)", c.na * c.nc, c.n_uav);
     if (c.reward_mode < UAVTRACK_REWARD_RAW || c.reward_mode > UAVTRACK_REWARD_PMI)
         return fail("reward_mode must be 0 (raw), 1 (mean) or 2 (pmi) (got %d)", c.reward_mode);
     if (c.horizon < 0) return fail("horizon must be >= 0");
@@ -131,7 +133,7 @@ int validate(const uavtrack_config &c)
 
 // MAAC-R scratch for deferred scoring of up to `steps` steps per chunk (grow-only).  Per step: the pair
 // list and its score array at their worst case (every pair within dp), the neighbour records, and observation /
-// term buffers for callers that pass NULL.  UAVTRACK_PMI_SCRATCH_MB bounds it (default 2048 MiB).
+// term buffers for callers that pass NULL.  UAVTRACK_PMI_SCRATCH_MB bounds it (default 8192 MiB; INTEGRATION.md: footprint).
 int ensure_pmi_scratch(uavtrack_env *env, int32_t steps, hipStream_t st)
 {
     const uavtrack_config &c = env->cfg;
@@ -139,7 +141,8 @@ int ensure_pmi_scratch(uavtrack_env *env, int32_t steps, hipStream_t st)
     // slots per step: every pair within dp at worst -- twice that, because the single-wavefront rollout variant hands out
     // pair-list slots in blocks and what a block has left when a step does not fit goes to dummies (less than that step's
     // pairs each time: never more than one dummy per real pair), plus a block per workgroup for the end of the launch
-    const size_t pairs_step = BN * (c.n_uav - 1) + (size_t)env->geo.groups * 64 + 1;
+    // (only the pooled geometry pays the doubling: the 4-wave one reserves exactly what a step emits)
+    const size_t pairs_step = env->geo.lone ? BN * (c.n_uav - 1) + (size_t)env->geo.groups * 64 + 1 : BN * (c.n_uav - 1) / 2 + 1;
     const size_t rec_bytes = (size_t)nbrec_words(c.n_uav) * 4;
     const size_t per_step = pairs_step * (sizeof(uint2) + 4) + BN * rec_bytes + BN * UAVTRACK_OBS_DIM * 4 + (size_t)c.n_envs * 4;
     size_t budget = (size_t)8192 << 20;        // (of 288 GB: a 200-step rollout of the reference shape stays one chunk)
@@ -151,22 +154,34 @@ int ensure_pmi_scratch(uavtrack_env *env, int32_t steps, hipStream_t st)
     if (cap > steps) cap = steps;
     if (cap <= env->pmi_steps_cap) return 0;
     HIP_TRY(hipStreamSynchronize(st));
+    // the larger buffers first, the old ones released only once all of them exist: a failed allocation leaves the handle
+    // as it was (still good for chunks of the old size)
+    const size_t S = (size_t)cap;
+    uint2 *n_pairs = nullptr; float *n_scores = nullptr, *n_obs = nullptr, *n_rsum = nullptr; uint32_t *n_rec = nullptr;
+    hipError_t e = dmalloc(&n_pairs, S * pairs_step);
+    if (e == hipSuccess) e = dmalloc(&n_scores, S * pairs_step);
+    if (e == hipSuccess) e = dmalloc(&n_rec, S * BN * nbrec_words(c.n_uav));
+    if (e == hipSuccess) e = dmalloc(&n_obs, S * BN * UAVTRACK_OBS_DIM);
+    if (e == hipSuccess) e = dmalloc(&n_rsum, S * (size_t)c.n_envs);
+    if (e != hipSuccess) {
+        void *fresh[] = {n_pairs, n_scores, n_rec, n_obs, n_rsum};
+        for (void *q : fresh)
+            if (q) (void)hipFree(q);
+        (void)hipGetLastError();
+        return fail("MAAC-R scratch for %lld steps per chunk (%.1f MiB) could not be allocated: %s; lower UAVTRACK_PMI_SCRATCH_MB",
+                    (long long)cap, (double)(S * per_step) / 1048576.0, hipGetErrorString(e));
+    }
     void *old[] = {env->pairs, env->scores, env->nbrec, env->obs_tmp, env->rsum};
     for (void *q : old)
         if (q) (void)hipFree(q);
-    env->pairs = nullptr; env->scores = nullptr; env->nbrec = nullptr; env->obs_tmp = nullptr; env->rsum = nullptr;
-    env->pmi_steps_cap = 0;
-    const size_t S = (size_t)cap;
-    HIP_TRY(dmalloc(&env->pairs, S * pairs_step));
-    HIP_TRY(dmalloc(&env->scores, S * pairs_step));
-    HIP_TRY(dmalloc(&env->nbrec, S * BN * nbrec_words(c.n_uav)));
-    HIP_TRY(dmalloc(&env->obs_tmp, S * BN * UAVTRACK_OBS_DIM));
-    HIP_TRY(dmalloc(&env->rsum, S * (size_t)c.n_envs));
+    env->pairs = n_pairs; env->scores = n_scores; env->nbrec = n_rec; env->obs_tmp = n_obs; env->rsum = n_rsum;
     if (!env->pair_count) {
         HIP_TRY(dmalloc(&env->pair_count, 1));
         HIP_TRY(hipMemsetAsync(env->pair_count, 0, sizeof(unsigned), st));
         HIP_TRY(dmalloc(&env->pair_total, 1));
         HIP_TRY(hipMemsetAsync(env->pair_total, 0, sizeof(unsigned long long), st));
+        HIP_TRY(dmalloc(&env->pmi_flags, 2));
+        HIP_TRY(hipMemsetAsync(env->pmi_flags, 0, 2 * sizeof(unsigned), st));
     }
     env->pmi_steps_cap = (int32_t)cap;
     return 0;
@@ -276,6 +291,13 @@ int uavtrack_create(const uavtrack_config *cfg, uavtrack_env **out)
     if (env->geo.wgs == 0) {
         delete env;
         return fail("uavtrack_create: no workgroup geometry for n_uav=%d", cfg->n_uav);
+    }
+    // specialised swarms of up to 64 UAVs count neighbours in the high part of an exact fp32 integer sum (step_kernel.hip
+    // act_bias_shape): n_uav * (K + na * nc) must stay below 2^24 there (the generic kernel keeps a separate count)
+    if (env->geo.specialised && cfg->n_uav <= 64 && (int64_t)cfg->n_uav * cfg->n_uav * cfg->na * cfg->nc * 4 >= ((int64_t)1 << 24)) {
+        delete env;
+        return fail("uavtrack_create: na * nc = %d actions is beyond what the specialised kernel of a %d-UAV swarm supports "
+                    "(n_uav^2 * na * nc must stay below 2^22)", cfg->na * cfg->nc, cfg->n_uav);
     }
     env->base.E = env->geo.envs_per_wg;
     env->geo_short = cfg->reward_mode == UAVTRACK_REWARD_PMI ? plan_geometry(*cfg, prop.multiProcessorCount * 4, false) : env->geo;
@@ -424,17 +446,17 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
     const int hp = pmi_padded_hidden(hidden);
     const size_t HP = (size_t)hp, n_dev = 12 * HP + 3 * HP + 3 * HP * HP + HP + HP + 1;
     const size_t x6_off = (n_dev + 3) & ~(size_t)3, x6_len = pmi_x6_floats(hp);     // the bf16 planes, 16-B aligned
-    const size_t h3_off = x6_off + x6_len, h3_len = pmi_h3_floats(hp);               // the f16 planes behind them
-    const size_t l1_off = h3_off + h3_len, l1_len = pmi_l1_floats(hp);               // ... the branch layers' f16 planes
-    const size_t t3_off = l1_off + l1_len, t3_len = h3_len;                           // ... and fc1 block-scaled (pmi_score_t3_kernel)
+    const size_t l1_off = x6_off + x6_len, l1_len = pmi_l1_floats(hp);               // the branch layers' f16 planes behind them
+    const size_t t3_off = l1_off + l1_len, t3_len = pmi_t3_floats(hp);               // ... and fc1 block-scaled (pmi_score_t3_kernel)
     if (env->pmi.n_floats != n_dev) {
         HIP_TRY(hipStreamSynchronize(st));
         if (env->pmi.blob) (void)hipFree(env->pmi.blob);
         env->pmi = PmiWeights();
         HIP_TRY(dmalloc(&env->pmi.blob, t3_off + t3_len));
     }
-    bool h3_ok = h3_len != 0;
+    bool h3_ok = t3_len != 0;
     float s1 = 1.0f, tw = 1.0f;
+    float rng_inv[3] = {0.0f, 0.0f, 0.0f};
     {   // fc1 goes up in the scorer's register order; the copy has completed before `packed` dies
         std::vector<float> padded(n_dev, 0.0f), packed(n_dev);
         const float *src = folded;
@@ -461,24 +483,29 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
             pack_pmi_x6(padded.data(), planes.data(), hp);
             HIP_TRY(hipMemcpyAsync(env->pmi.blob + x6_off, planes.data(), x6_len * 4, hipMemcpyHostToDevice, st));
         }
-        // The f16 x 3 scorer (pmi_score_h3_kernel) needs every MFMA operand inside f16's range (65504): the fc1 weights
+        // The f16 x 3 scorer (pmi_score_t3_kernel) needs every MFMA operand inside f16's range (65504): the fc1 weights
         // are known here, the branch activations are bounded from the ranges of the observation products x = la_i * la_j
         // (uav.py:156-197: normalised offsets and action differences within [-1, 1], heading terms within +-(1 + v_t/v_u),
         // positions / dc taken up to three field lengths outside the box).  A network beyond half that range keeps the
         // bf16 x 6 kernel (bf16 has fp32's exponent).
-        std::vector<uint16_t> planes3(h3_len * 2);
         if (h3_ok) {
             const uavtrack_config &c = env->cfg;
             const double vr = 1.0 + c.t_v_max / c.u_v_max, pos = 4.0 * std::fmax(c.x_max, c.y_max) / c.dc;
             const double xb[12] = {1, 1, 4, 4, 1, 1, 1, vr * vr, vr * vr, pos * pos, pos * pos, 1};
             const float *pw = padded.data();
             double act_max = 0.0, w_max = 0.0, w1_max = 0.0;
+            double gain[3] = {0.0, 0.0, 0.0}, bias[3] = {0.0, 0.0, 0.0};      // per branch: max_u sum_k |w_uk|, max_u |b_u|
             const int fan[3] = {5, 4, 3};
             int k0 = 0;
             for (int br = 0; br < 3; ++br) {              // W[fan][HP] then b[HP]
                 for (size_t u = 0; u < HP; ++u) {
-                    double a = std::fabs(pw[(size_t)fan[br] * HP + u]);
-                    for (int k = 0; k < fan[br]; ++k) a += std::fabs(pw[(size_t)k * HP + u]) * xb[k0 + k];
+                    double a = std::fabs(pw[(size_t)fan[br] * HP + u]), gsum = 0.0;
+                    bias[br] = std::fmax(bias[br], a);
+                    for (int k = 0; k < fan[br]; ++k) {
+                        a += std::fabs(pw[(size_t)k * HP + u]) * xb[k0 + k];
+                        gsum += std::fabs(pw[(size_t)k * HP + u]);
+                    }
+                    gain[br] = std::fmax(gain[br], gsum);
                     act_max = std::fmax(act_max, a);
                 }
                 pw += (size_t)(fan[br] + 1) * HP;
@@ -501,11 +528,20 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
             };
             s1 = scale_for(act_max, 512.0);
             tw = scale_for(w1_max, 32000.0);
+            // The run-time watch of the f16 kernel (pmi_kernel.hip, PmiParams::rng_inv).  The bounds above come from NOMINAL
+            // observation ranges; the uav.py:165 weight 1 / min(d, 1) lets a UAV next to the origin exceed them without
+            // limit.  An activation of branch br stays below 60000 / S1 while |x| <= (60000 / S1 - max|b|) / max_u sum_k|w_uk|
+            // over the branch's inputs, and an input splits into normal f16 planes below 30000 (its remainder is scaled by 2^11):
+            // the kernel compares the largest |x| of a tile with the smaller of the two and has the chunk re-scored by the
+            // bf16 kernel when it is exceeded.
+            for (int br = 0; br < 3; ++br) {
+                double lim = 30000.0;
+                if (gain[br] > 0.0) lim = std::fmin(lim, (60000.0 / (double)s1 - bias[br]) / gain[br]);
+                rng_inv[br] = lim > 0.0 ? (float)(1.0 / lim) : INFINITY;
+            }
         }
         std::vector<uint16_t> planes1(l1_len * 2);
         if (h3_ok) {
-            pack_pmi_h3(padded.data(), planes3.data(), hp);
-            HIP_TRY(hipMemcpyAsync(env->pmi.blob + h3_off, planes3.data(), h3_len * 4, hipMemcpyHostToDevice, st));
             pack_pmi_l1(padded.data(), planes1.data(), hp, s1);
             HIP_TRY(hipMemcpyAsync(env->pmi.blob + l1_off, planes1.data(), l1_len * 4, hipMemcpyHostToDevice, st));
         }
@@ -518,14 +554,18 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
         HIP_TRY(hipStreamSynchronize(st));
     }
     env->pmi.x6 = x6_len ? env->pmi.blob + x6_off : nullptr;
-    env->pmi.h3 = h3_ok ? env->pmi.blob + h3_off : nullptr;
     env->pmi.l1 = h3_ok ? env->pmi.blob + l1_off : nullptr;
     env->pmi.t3 = h3_ok ? env->pmi.blob + t3_off : nullptr;
     env->pmi.t3_s1 = s1;
     env->pmi.t3_t = tw;
+    for (int k = 0; k < 3; ++k) env->pmi.rng_inv[k] = rng_inv[k];
     env->pmi.hidden = hp;
     env->pmi.n_floats = n_dev;
     if (ensure_pmi_scratch(env, 1, st)) return 1;
+    if (!pmi_scheme_available(env, env->pmi_scheme))
+        return fail("uavtrack_set_pmi_weights: these weights (hidden %d%s) cannot run on the pinned scorer scheme %d "
+                    "(uavtrack_set_pmi_scheme); pin UAVTRACK_PMI_AUTO or a scheme that takes them",
+                    hidden, h3_ok ? "" : ", beyond f16's range", env->pmi_scheme);
     return 0;
 }
 
@@ -551,7 +591,38 @@ int uavtrack_pmi_inference(uavtrack_env *env, const float *x, int64_t n, float *
     HIP_TRY(launch_pmi_inference_prep(x, env->inf_obs, env->inf_pairs, (unsigned)n, st));
     HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(env->pair_count), (int)n, 1, st));
     HIP_TRY(launch_pmi_score(env, env->inf_obs, st, env->inf_pairs, scores, 2));
-    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(env->pair_count), 0, 1, st));
+    HIP_TRY(launch_pmi_counters_reset(env, st));
+    return 0;
+}
+
+int uavtrack_set_pmi_scheme(uavtrack_env *env, int32_t scheme)
+{
+    if (!env) return fail("uavtrack_set_pmi_scheme: null handle");
+    if (scheme < UAVTRACK_PMI_AUTO || scheme > UAVTRACK_PMI_FP32)
+        return fail("uavtrack_set_pmi_scheme: scheme %d is not one of enum uavtrack_pmi_scheme", scheme);
+    if (env->pmi.blob && !pmi_scheme_available(env, scheme))
+        return fail("uavtrack_set_pmi_scheme: the loaded weights (hidden %d padded%s) cannot run on scheme %d: F16X3 and BF16X6 take "
+                    "widths 64 / 96 / 128, F16X3 only networks inside f16's range", env->pmi.hidden, env->pmi.t3 ? "" : ", beyond f16's range", scheme);
+    env->pmi_scheme = scheme;
+    return 0;
+}
+
+int uavtrack_pmi_info(uavtrack_env *env, int64_t out[4], void *stream)
+{
+    if (!env || !out) return fail("uavtrack_pmi_info: null argument");
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (!env->pmi.blob) return 0;
+    out[0] = pmi_effective_scheme(env);
+    out[1] = env->pmi.hidden;
+    out[2] = env->pmi.t3 ? 1 : 0;
+    if (env->pmi_flags) {
+        ON_DEVICE(env->cfg.device_id);
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        unsigned v[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(v, env->pmi_flags, sizeof v, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        out[3] = v[1];
+    }
     return 0;
 }
 
@@ -629,7 +700,8 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
         p.covered = covered_t;
         p.done = done ? done + (size_t)t0 * c.n_envs : nullptr;
         p.tpos = env->tpos ? env->tpos + (size_t)t0 * c.n_envs * c.m_targets : nullptr;
-        const Geometry *geo = n < kPmiShortLaunch ? &env->geo_short : &env->geo;
+        // (short launches: 4-wave groups; long ones: the handle's geometry where its kernel variant exists -- launch_rollout)
+        const Geometry *geo = n < kPmiShortLaunch ? &env->geo_short : nullptr;
         HIP_TRY(timed_launch(env, UAVTRACK_PROF_ROLLOUT, st, [&] { return launch_rollout(env, p, st, pol.policy, geo); }));
         // the actor of the next chunk starts from this chunk's last observation (a lane reads its own row
         // once, at launch start, before it writes anything: the scratch buffer may be reused in place)
@@ -827,6 +899,16 @@ int uavtrack_get_profile(uavtrack_env *env, double *ms, int64_t *launches, void 
         }
     }
     drop_profile(env);
+    return 0;
+}
+
+int uavtrack_launch_info(uavtrack_env *env, int64_t out[4])
+{
+    if (!env || !out) return fail("uavtrack_launch_info: null argument");
+    out[0] = env->last_launch.wgs;
+    out[1] = env->last_launch.envs_per_wg;
+    out[2] = env->last_launch.groups;
+    out[3] = env->last_launch.lone;
     return 0;
 }
 

@@ -113,11 +113,11 @@ __host__ __device__ inline int nbrec_words(int N) { return nbrec_mask_words(N) +
 struct PmiWeights {
     float *blob = nullptr;   // device, folded layout of uavtrack_set_pmi_weights; behind it the bf16 planes of fc1
     const void *x6 = nullptr; // -> into blob: fc1 as three bf16 planes in MFMA operand order (pack_pmi_x6), or null
-    const void *h3 = nullptr; // -> into blob: fc1 as two f16 planes (hi, lo * 2^11) in MFMA operand order (pack_pmi_h3), or null
-                              //    (also null when the network's weights / activation bounds do not fit f16's range)
     const void *l1 = nullptr; // -> into blob: the branch layers as f16 planes in MFMA A-operand order (pack_pmi_l1), with t3
-    const void *t3 = nullptr; // -> into blob: fc1 block-scaled as two f16 planes (f16(T w), remainder) for pmi_score_t3_kernel, with h3
+    const void *t3 = nullptr; // -> into blob: fc1 block-scaled as two f16 planes (f16(T w), remainder) for pmi_score_t3_kernel,
+                              //    or null when the network's weights / activation bounds do not fit f16's range
     float t3_s1 = 1.0f, t3_t = 1.0f;   // the powers of two folded into the branch layers (S1) and fc1 (T) of the t3 planes
+    float rng_inv[3] = {0.0f, 0.0f, 0.0f};   // 1 / the largest |x| per branch input the f16 planes take (pmi_kernel.hip, PmiParams)
     int32_t hidden = 0;
     size_t n_floats = 0;
 };
@@ -143,8 +143,11 @@ struct uavtrack_env {
     // on a quarter of the workgroups; the single-wavefront variant's block reservations pay off over many steps, and a
     // launch that starts with an empty pool waits for its first one)
     uavtrack::Geometry geo_short;
+    uavtrack::Geometry last_launch;   // geometry of the most recent rollout launch (uavtrack_launch_info)
     uavtrack::PmiWeights pmi;
     int32_t n_cus = 0;           // compute units of the device (grid of the persistent scorer)
+    int32_t pmi_scheme = 0;      // uavtrack_set_pmi_scheme: UAVTRACK_PMI_AUTO or a pinned scorer
+    unsigned *pmi_flags = nullptr;   // device [2]: the f16 scorer's range flag, chunks re-scored by the wide-range kernel
     float *actor_w = nullptr;    // device blob of uavtrack_set_actor_weights (actor.h layout)
     int32_t actor_hidden = 0;
     // MAAC-R scratch for `pmi_steps_cap` steps of deferred scoring (rewards never feed back into the
@@ -177,7 +180,7 @@ namespace uavtrack {
 Geometry plan_geometry(const uavtrack_config &cfg, int n_simd, bool allow_small_grid = true);
 enum { kPolicyGiven = 0, kPolicyGreedy = 1, kPolicyActor = 2 };   // where a rollout's actions come from
 // (geo: the launch geometry, default the handle's own; MAAC-R launches of a few steps use env->geo_short)
-hipError_t launch_rollout(const uavtrack_env *env, const StepParams &p, hipStream_t stream, int policy = kPolicyGiven,
+hipError_t launch_rollout(uavtrack_env *env, const StepParams &p, hipStream_t stream, int policy = kPolicyGiven,
                           const Geometry *geo = nullptr);
 size_t rollout_lds_bytes(const Geometry &g, int policy);   // dynamic LDS of a rollout launch with that policy
 
@@ -190,14 +193,16 @@ constexpr int kPmiX6MaxHidden = 128;                // widest layer whose three 
 constexpr int kPmiX6MinHidden = 64;                 // (narrower layers have fewer k-steps than the producer has pairs to hide)
 inline size_t pmi_x6_floats(int hp) { return hp >= kPmiX6MinHidden && hp <= kPmiX6MaxHidden ? (size_t)3 * hp * hp * 3 / 2 : 0; }   // 3 planes x 2 B
 void pack_pmi_x6(const float *abi_blob, uint16_t *planes, int hidden);
-inline size_t pmi_h3_floats(int hp) { return hp >= kPmiX6MinHidden && hp <= kPmiX6MaxHidden ? (size_t)3 * hp * hp : 0; }   // 2 planes x 2 B
-void pack_pmi_h3(const float *abi_blob, uint16_t *planes, int hidden);
-void pack_pmi_t3(const float *abi_blob, uint16_t *planes, int hidden, float T);             // (size: pmi_h3_floats)
-inline size_t pmi_l1_floats(int hp) { return pmi_h3_floats(hp) ? (size_t)(hp / 32) * 3 * 3 * 64 * 8 / 2 : 0; }   // [w][branch][3 planes][lane][8] x 2 B
+inline size_t pmi_t3_floats(int hp) { return hp >= kPmiX6MinHidden && hp <= kPmiX6MaxHidden ? (size_t)3 * hp * hp : 0; }   // 2 planes x 2 B
+void pack_pmi_t3(const float *abi_blob, uint16_t *planes, int hidden, float T);
+inline size_t pmi_l1_floats(int hp) { return pmi_t3_floats(hp) ? (size_t)(hp / 32) * 3 * 3 * 64 * 8 / 2 : 0; }   // [w][branch][3 planes][lane][8] x 2 B
 void pack_pmi_l1(const float *abi_blob, uint16_t *planes, int hidden, float S1);
 // (pairs / scores / n_uav default to the handle's MAAC-R scratch and swarm size; uavtrack_pmi_inference passes its own)
 hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream_t stream, const uint2 *pairs = nullptr,
                             float *scores = nullptr, int n_uav = 0);
+int pmi_effective_scheme(const uavtrack_env *env);              // enum uavtrack_pmi_scheme, never AUTO
+bool pmi_scheme_available(const uavtrack_env *env, int scheme);
+hipError_t launch_pmi_counters_reset(const uavtrack_env *env, hipStream_t stream);
 hipError_t launch_pmi_inference_prep(const float *x, float *obs2, uint2 *pairs, unsigned n, hipStream_t stream);
 hipError_t launch_pmi_finalize(const uavtrack_env *env, int steps, float *reward, float *rsum, hipStream_t stream);
 hipError_t launch_ep_reward(const uavtrack_env *env, int steps, const float *rsum, float *ep_sums, bool add, hipStream_t stream);

@@ -37,6 +37,7 @@ class UavtrackConfig(C.Structure):
 
 ACTOR_SAMPLE, ACTOR_ARGMAX = 0, 1   # enum in include/uavtrack.h
 PROF_CLASSES = ("rollout", "scorer", "mix", "ep_sums")   # UAVTRACK_PROF_* in include/uavtrack.h
+PMI_SCHEMES = ("auto", "f16x3", "bf16x6", "fp32")         # enum uavtrack_pmi_scheme
 
 # name -> (restype, argtypes); every symbol declared in include/uavtrack.h
 SIGNATURES = {
@@ -50,6 +51,8 @@ SIGNATURES = {
     "uavtrack_set_episodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "uavtrack_get_episodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "uavtrack_set_pmi_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
+    "uavtrack_set_pmi_scheme": (C.c_int, [C.c_void_p, C.c_int32]),
+    "uavtrack_pmi_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
     "uavtrack_pmi_inference": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "uavtrack_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.c_void_p]),
     "uavtrack_step_accumulate": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.c_void_p]),
@@ -65,6 +68,7 @@ SIGNATURES = {
     "uavtrack_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "uavtrack_get_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_void_p]),
     "uavtrack_kernel_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "uavtrack_launch_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
 }
 
 _lib = None

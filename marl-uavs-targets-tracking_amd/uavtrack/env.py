@@ -294,6 +294,28 @@ class BatchedUavEnv:
         _lib.check(self._lib.uavtrack_set_pmi_weights(self._h, C.c_void_p(blob.ctypes.data), blob.size, hidden,
                                                       self._stream()), "uavtrack_set_pmi_weights")
 
+    def set_pmi_scheme(self, scheme: str = "auto") -> None:
+        """Pin the MAAC-R pair scorer: "auto" (default: the fastest the weights allow), "f16x3", "bf16x6" or "fp32"
+        (uavtrack_set_pmi_scheme).  Raises if the loaded weights cannot run on it."""
+        if scheme not in _lib.PMI_SCHEMES:
+            raise ValueError(f"scheme must be one of {_lib.PMI_SCHEMES}")
+        _lib.check(self._lib.uavtrack_set_pmi_scheme(self._h, C.c_int32(_lib.PMI_SCHEMES.index(scheme))), "uavtrack_set_pmi_scheme")
+
+    def pmi_info(self) -> Dict[str, object]:
+        """{"scheme": the scorer the next MAAC-R step launches (None without weights), "hidden_padded", "f16_range_ok": the
+        host-side range guard passed, "rescored_chunks": chunks the wide-range kernel scored again because an operand left
+        f16's range at run time}.  Synchronises the stream."""
+        out = (C.c_int64 * 4)()
+        _lib.check(self._lib.uavtrack_pmi_info(self._h, out, self._stream()), "uavtrack_pmi_info")
+        return dict(scheme=_lib.PMI_SCHEMES[out[0]] if out[0] else None, hidden_padded=int(out[1]), f16_range_ok=bool(out[2]),
+                    rescored_chunks=int(out[3]))
+
+    def launch_info(self) -> Dict[str, int]:
+        """Geometry of the most recent rollout launch (uavtrack_launch_info)."""
+        out = (C.c_int64 * 4)()
+        _lib.check(self._lib.uavtrack_launch_info(self._h, out), "uavtrack_launch_info")
+        return dict(workgroup=int(out[0]), envs_per_workgroup=int(out[1]), workgroups=int(out[2]), single_wavefront_variant=int(out[3]))
+
     def pmi_inference(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """PMINetwork.inference (PMINet.py:64-72) on a batch of pair inputs x [n, 12] (= la_i * la_j, uav.py:281) with the
         uploaded weights, on the MAAC-R scorer kernels -> scores [n]."""

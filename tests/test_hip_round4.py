@@ -169,3 +169,236 @@ def test_pmi_training_selection_on_device_against_reference(uavtrack):
     for k in range(b2 // bs):
         np.testing.assert_allclose(seen[2 * k], z["out_1_2"][k], rtol=0, atol=2e-4)
         np.testing.assert_allclose(seen[2 * k + 1], z["out_1_3"][k], rtol=0, atol=2e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# every scorer the library can dispatch.  Reference: PMINetwork.forward / inference, PMINet.py:41-72.
+
+def _scaled_identity(sd, how):
+    """The SAME function as `sd` (ReLU is positively homogeneous; the factors are powers of two, so the BatchNorm fold
+    scales exactly), but with operands that trip the host-side f16 range guard of uavtrack_set_pmi_weights:
+    "big_fc1": folded fc1 x 2^16 (|w| far past 32 000), fc2 x 2^-16;  "big_branch": folded branch layers x 2^14 (activation
+    bound far past 32 000), fc1's input columns x 2^-14."""
+    out = {k: np.array(v, dtype=np.float32) for k, v in sd.items()}
+    if how == "big_fc1":
+        s = np.float32(2.0 ** 16)
+        out["bn1.weight"] *= s; out["bn1.bias"] *= s
+        out["fc2.weight"] /= s
+    elif how == "big_branch":
+        s = np.float32(2.0 ** 14)
+        for bn in ("bn_comm", "bn_obs", "bn_boundary_state"):
+            out[bn + ".weight"] *= s; out[bn + ".bias"] *= s
+        out["fc1.weight"] /= s
+    else:
+        raise ValueError(how)
+    return out
+
+
+SCHEME_CASES = [("auto", None, "f16x3"), ("bf16x6", None, "bf16x6"), ("fp32", None, "fp32"),
+                ("auto", "big_fc1", "bf16x6"), ("auto", "big_branch", "bf16x6")]
+
+
+@pytest.mark.parametrize("pin,trip,expect", SCHEME_CASES)
+def test_pmi_goldens_on_every_scorer(uavtrack, pmi_state_dict, pmi_state_dict_h64, pin, trip, expect):
+    """g4 (H = 128) and g4b (H = 64), the reference's recorded MAAC-R rewards, on each scorer kernel: the default f16 x 3,
+    bf16 x 6 and fp32 MFMA pinned through uavtrack_set_pmi_scheme, and bf16 x 6 reached the way production reaches it --
+    the f16 range guard turning the network away (the same network function with one layer scaled by a power of two and the
+    next one scaled back).  uavtrack_pmi_info says which kernel the handle launches."""
+    for name in ("g4_n20m10_pmi", "g4b_n20m10_pmi_h64"):
+        z, meta = load_golden(name)
+        sd = pmi_state_dict_h64 if name.endswith("h64") else pmi_state_dict
+        if trip:
+            sd = _scaled_identity(sd, trip)
+        N, M = meta["n_uav"], meta["m_targets"]
+        E, T = len(meta["seeds"]), meta["steps"]
+        B = E * T
+        pick = lambda k: z[k][:, :T].reshape(B, -1)
+        kw = dict(n_envs=B, n_uav=N, m_targets=M, cooperative=0.3)
+        env = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(reward_mode=uavtrack.RewardMode.PMI, **kw))
+        env.set_pmi_scheme(pin)
+        env.set_pmi(sd)
+        info = env.pmi_info()
+        assert info["scheme"] == expect, info
+        assert info["f16_range_ok"] == (trip is None)
+        env.set_state(**{k: pick(k) for k in ("ux", "uy", "uh", "ua", "tx", "ty", "th")})
+        act = z["actions"].reshape(B, N).astype(np.int32)
+        orc = OracleEnv(OracleConfig(**kw), n_threads=8)
+        orc.pmi = OraclePmi.from_state_dict(sd)
+        inject(orc, host(env.get_state()))
+        ref = orc.step(act)
+        ok = ref["margin"] > 5e-3
+        obs, rew, _ = env.step(torch.from_numpy(act))
+        rew = rew.cpu().numpy()
+        np.testing.assert_allclose(rew[ok], z["reward"].reshape(B, N)[ok], rtol=0, atol=2e-5, err_msg=f"{name} {pin} {trip}")
+        np.testing.assert_allclose(rew[ok], ref["reward"][ok], rtol=0, atol=ATOL, err_msg=f"{name} {pin} {trip} vs oracle")
+        assert env.pmi_info()["rescored_chunks"] == 0          # nothing left f16's range: the stand-by kernel stayed idle
+        env.close()
+
+
+@pytest.mark.parametrize("pin,trip,expect", SCHEME_CASES)
+def test_pmi_inference_on_every_scorer(uavtrack, pmi_state_dict, pin, trip, expect):
+    """PMINetwork.inference alone (uavtrack_pmi_inference) on each scorer kernel against the fp64 forward: the adversarial
+    weights (every 3H-term sum a large cancellation) at 1e-5 of sum |terms|, the reference-initialised network at the plain
+    1e-5, and the tile loop's edges (fewer pairs than a tile, one more than a tile, fewer tiles than workgroups, none)."""
+    env = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(n_envs=1, n_uav=2, m_targets=1, cooperative=0.3,
+                                                    reward_mode=uavtrack.RewardMode.PMI))
+    env.set_pmi_scheme(pin)
+    rng = np.random.RandomState(11)
+    for hidden in (128, 64):
+        sd = adversarial_pmi_state_dict(hidden, seed=hidden)
+        if trip:
+            sd = _scaled_identity(sd, trip)
+        env.set_pmi(sd)
+        assert env.pmi_info()["scheme"] == expect
+        n = 3000 + hidden
+        x = rng.uniform(-1.0, 1.0, (n, 12)).astype(np.float32)
+        x[: n // 4] *= rng.uniform(0.0, 4.5, (n // 4, 1)).astype(np.float32) ** 2
+        got = env.pmi_inference(torch.from_numpy(x).cuda()).cpu().numpy().astype(np.float64)
+        ref, mag = pmi_forward_fp64(sd, x, want_scale=True)
+        # (the scaled-identity networks carry the factor 2^16 / 2^14 in their intermediate sums; the bound scales with them)
+        assert np.isfinite(got).all() and (np.abs(got - ref) <= 1e-5 * np.maximum(mag, 1.0)).all(), (hidden, np.abs(got - ref).max())
+    sd = _scaled_identity(pmi_state_dict, trip) if trip else pmi_state_dict
+    env.set_pmi(sd)
+    for n in (1, 31, 32, 33, 65, 257, 8191):
+        x = rng.uniform(-1.0, 1.0, (n, 12)).astype(np.float32)
+        got = env.pmi_inference(torch.from_numpy(x).cuda()).cpu().numpy().astype(np.float64)
+        ref = pmi_forward_fp64(sd, x)
+        assert got.shape == (n,) and np.abs(got - ref).max() < 1e-5, (n, np.abs(got - ref).max())
+    assert env.pmi_inference(torch.empty(0, 12, device="cuda")).shape == (0,)
+    env.close()
+
+
+def test_pmi_scheme_pinning_errors(uavtrack, pmi_state_dict):
+    """A pinned scheme the weights cannot run on is an error where it is pinned or where the weights arrive, never a silent
+    switch: f16 x 3 with a network beyond f16's range, the split kernels with a width they are not built for."""
+    env = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(n_envs=1, n_uav=2, m_targets=1, cooperative=0.3,
+                                                    reward_mode=uavtrack.RewardMode.PMI))
+    assert env.pmi_info()["scheme"] is None
+    env.set_pmi(_scaled_identity(pmi_state_dict, "big_fc1"))
+    with pytest.raises(RuntimeError, match="f16"):
+        env.set_pmi_scheme("f16x3")
+    assert env.pmi_info()["scheme"] == "bf16x6"
+    env.set_pmi(pmi_state_dict)
+    env.set_pmi_scheme("f16x3")
+    with pytest.raises(RuntimeError, match="pinned"):
+        env.set_pmi(_scaled_identity(pmi_state_dict, "big_branch"))
+    env.set_pmi_scheme("auto")
+    from test_hip_parity import random_pmi_state_dict
+    env.set_pmi(random_pmi_state_dict(200, 1))
+    assert env.pmi_info() == dict(scheme="fp32", hidden_padded=224, f16_range_ok=False, rescored_chunks=0)
+    with pytest.raises(RuntimeError, match="widths"):
+        env.set_pmi_scheme("bf16x6")
+    with pytest.raises(ValueError):
+        env.set_pmi_scheme("h3")
+    env.close()
+
+
+def test_pmi_f16_range_watch_rescoring_near_origin(uavtrack, pmi_state_dict):
+    """the uav.py:165 weight 1 / min(d, 1) is unbounded next to the origin, so observations -- and the scorer's
+    inputs la_i * la_j -- can leave the range the host-side f16 guard assumed.  (1) The scorer alone on inputs up to 2e6:
+    the f16 kernel must notice (uavtrack_pmi_info counts the chunk) and the scores must be the wide-range kernel's, i.e.
+    within the fp32 bound of the fp64 forward; ordinary inputs leave the counter alone.  (2) A MAAC-R step with two UAVs
+    a fraction of a millimetre apart, a millimetre from the origin: weighted-mean observation rows ~700 times the nominal
+    size, products ~10^6 -- the rewards equal those of a handle pinned to bf16 x 6 bit for bit, and every other environment
+    of the batch still agrees with the oracle."""
+    B, N, M = 8, 20, 10
+    kw = dict(n_envs=B, n_uav=N, m_targets=M, cooperative=0.3)
+    cfg = uavtrack.EnvConfig(reward_mode=uavtrack.RewardMode.PMI, **kw)
+    a, b = uavtrack.BatchedUavEnv(cfg), uavtrack.BatchedUavEnv(cfg)
+    b.set_pmi_scheme("bf16x6")
+    for e in (a, b):
+        e.set_pmi(pmi_state_dict)
+        e.reset(seed=3)
+    assert a.pmi_info()["scheme"] == "f16x3"
+    # (1) the network alone
+    rng = np.random.RandomState(5)
+    x = rng.uniform(-1.0, 1.0, (4000, 12)).astype(np.float32)
+    got = a.pmi_inference(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert a.pmi_info()["rescored_chunks"] == 0 and np.abs(got - pmi_forward_fp64(pmi_state_dict, x)).max() < 1e-5
+    xl = x.copy()
+    xl[100:140] *= rng.uniform(1e3, 2e6, (40, 1)).astype(np.float32)          # a few rows far outside f16's reach
+    got = a.pmi_inference(torch.from_numpy(xl).cuda()).cpu().numpy().astype(np.float64)
+    ref, mag = pmi_forward_fp64(pmi_state_dict, xl, want_scale=True)
+    assert a.pmi_info()["rescored_chunks"] == 1
+    assert np.isfinite(got).all() and (np.abs(got - ref) <= 1e-5 * np.maximum(mag, 1.0)).all(), np.abs(got - ref).max()
+    np.testing.assert_array_equal(got, b.pmi_inference(torch.from_numpy(xl).cuda()).cpu().numpy().astype(np.float64))
+    # (2) the step.  Environment 2: UAVs 0 and 1 END their move next to the origin and to each other
+    st = host(a.get_state())
+    act = rng.randint(0, 12, size=(B, N)).astype(np.int32)
+    for i, (fx, fy, h) in enumerate(((1.0e-3, 1.0e-3, 0.7), (1.2e-3, 0.8e-3, 0.8))):
+        st["uh"][2, i] = h
+        st["ux"][2, i] = np.float32(fx - 20.0 * np.cos(np.float32(h)))
+        st["uy"][2, i] = np.float32(fy - 20.0 * np.sin(np.float32(h)))
+    for e in (a, b):
+        e.set_state(**{k: v for k, v in st.items() if k not in ("step_count", "episode")})
+    orc = OracleEnv(OracleConfig(**kw), n_threads=4)
+    orc.pmi = OraclePmi.from_state_dict(pmi_state_dict)
+    inject(orc, host(a.get_state()))
+    ref = orc.step(act)
+    obs_a, rew_a, _ = a.step(torch.from_numpy(act))
+    obs_b, rew_b, _ = b.step(torch.from_numpy(act))
+    pos = host(a.get_state())
+    assert max(abs(pos["ux"][2, 0]), abs(pos["uy"][2, 0]), abs(pos["ux"][2, 1]), abs(pos["uy"][2, 1])) < 2e-3
+    big = np.abs(obs_a.cpu().numpy()[2, :2, :9]).max()
+    assert big > 100.0, f"the scenario did not produce an out-of-range observation (max |obs| {big})"
+    assert a.pmi_info()["rescored_chunks"] == 2 and b.pmi_info()["rescored_chunks"] == 0
+    assert torch.equal(rew_a, rew_b) and torch.equal(obs_a, obs_b)
+    assert torch.isfinite(rew_a).all()
+    ok = ref["margin"] > 1e-3
+    ok[2] = False               # (its scores hang on a weight of ~700 +- 0.1 %: fp32 poses against fp64 ones, not comparable)
+    assert ok.sum() >= 5
+    np.testing.assert_allclose(rew_a.cpu().numpy()[ok], ref["reward"][ok], rtol=0, atol=ATOL)
+    # the flag is per chunk: the next, ordinary step is scored by the f16 kernel alone again
+    a.reset(seed=4)
+    a.step(torch.from_numpy(act))
+    assert a.pmi_info()["rescored_chunks"] == 2
+    a.close(); b.close()
+
+
+def test_maac_r_launch_geometry_follows_the_kernel_variant(uavtrack, pmi_state_dict):
+    """a MAAC-R launch of 16+ steps uses the single-wavefront geometry only where the kernel variant
+    built for it (pair-list slots from a pool) exists -- every output requested, no extras.  A launch without the terms, or
+    with the automatic reset or the target trace, keeps 256-thread groups (the 4-wave emission path on 64-thread groups
+    makes one global reservation per workgroup-step on four times the groups) -- and all of them give the same bits."""
+    B, N, M, T = 512, 20, 10, 20
+    cfg = uavtrack.EnvConfig(n_envs=B, n_uav=N, m_targets=M, cooperative=0.3, reward_mode=uavtrack.RewardMode.PMI, horizon=50)
+    act = torch.randint(0, 12, (T, B, N), dtype=torch.int32, device="cuda", generator=torch.Generator("cuda").manual_seed(2))
+    outs = {}
+    for label, kwargs in (("allout", {}), ("no_terms", dict(want_terms=False)), ("trace", dict(want_targets=True)),
+                          ("autoreset", dict(auto_reset_seed=5)), ("short", None)):
+        env = uavtrack.BatchedUavEnv(cfg)
+        env.set_pmi(pmi_state_dict)
+        env.reset(seed=8)
+        assert env.kernel_info()["workgroup"] == 64           # the handle's own (small-grid) geometry
+        if kwargs is None:
+            res = env.step_many(act[:8])
+        else:
+            res = env.step_many(act, **kwargs)
+        li = env.launch_info()
+        if label == "allout":
+            assert li["workgroup"] == 64 and li["single_wavefront_variant"] == 1, li
+        else:
+            assert li["workgroup"] == 256 and li["single_wavefront_variant"] == 0, (label, li)
+        outs[label] = res
+        env.close()
+    for label in ("no_terms", "trace", "autoreset"):
+        assert torch.equal(outs[label]["reward"], outs["allout"]["reward"]), label
+        assert torch.equal(outs[label]["obs"], outs["allout"]["obs"]), label
+    assert torch.equal(outs["short"]["reward"], outs["allout"]["reward"][:8])
+
+
+def test_lds_need_follows_reward_mode(uavtrack):
+    """the symmetric duplicate term's LDS region exists in the MAAC reward mode only; MAAC-G / MAAC-R handles
+    do not reserve it (more environments per workgroup, larger swarms fit)."""
+    raw = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(n_envs=64, n_uav=50, m_targets=25))
+    mean = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(n_envs=64, n_uav=50, m_targets=25, cooperative=0.3))
+    ki_r, ki_m = raw.kernel_info(), mean.kernel_info()
+    assert ki_r["envs_per_workgroup"] == ki_m["envs_per_workgroup"] and ki_m["lds_bytes"] < ki_r["lds_bytes"]
+    # the largest swarm a workgroup takes (n_uav <= 512) with many targets: fits in either mode
+    for coop in (0.0, 0.3):
+        e = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(n_envs=2, n_uav=512, m_targets=64, cooperative=coop))
+        e.reset(seed=1)
+        obs, rew, _ = e.step(torch.zeros(2, 512, dtype=torch.int32))
+        assert torch.isfinite(rew).all()
+        e.close()
+    raw.close(); mean.close()

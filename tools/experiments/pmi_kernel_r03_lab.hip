@@ -26,6 +26,7 @@
 
 #include "internal.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 
@@ -58,6 +59,7 @@ __device__ __forceinline__ float half_wave_sum(float v)
 struct PmiParams {
     const float *blob;       // folded weights, layout of uavtrack_set_pmi_weights
     const void *x6;          // fc1 as three bf16 planes in MFMA B-operand order (pack_pmi_x6)
+    const void *h3;          // fc1 as two f16 planes (hi, lo * 2^11) in MFMA B-operand order (pack_pmi_h3), or null
     const void *l1;          // the three branch layers as f16 planes in MFMA A-operand order (pack_pmi_l1), with t3
     const void *t3;          // fc1 as two f16 planes of T * w (hi, unscaled remainder) for pmi_score_t3_kernel (pack_pmi_t3), or null
     float t3_scale;          // S1 * T: the power-of-two scale the t3 kernel's layer-2 accumulators carry (b1 goes in times this)
@@ -68,12 +70,6 @@ struct PmiParams {
     float *scores;           // one per pair, in pair-list order
     unsigned long long *pair_total;
     int32_t N;
-    // f16 range watch of pmi_score_t3_kernel: 1 / (largest |x| each branch's inputs may reach before an f16 operand could
-    // saturate; uavtrack_set_pmi_weights); a tile that exceeds one raises *range_flag, and the wide-range kernel launched
-    // behind it (gate != null: it returns at once while *gate == 0) scores the chunk again
-    float rng_inv[3];
-    unsigned *range_flag;
-    const unsigned *gate;
 };
 
 template <int H>
@@ -209,6 +205,7 @@ __global__ void __launch_bounds__(H * 2, 2) pmi_score_kernel(const PmiParams q)
             float4 *dst = reinterpret_cast<float4 *>(xs + (cur ^ 1) * 32 * 12 + tid * 12);
             dst[0] = x_next[0]; dst[1] = x_next[1]; dst[2] = x_next[2];
         }
+        const uint2 pr_this = pr_cur;
         pr_cur = pr_next;
         gather(tile + 2 * gridDim.x, pr_next, x_next);
         __syncthreads();                                    // activation tile and xs[cur ^ 1] complete
@@ -270,6 +267,24 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 // Workgroup barrier that orders LDS traffic only (outstanding global loads stay in flight; the compiler still waits for
 // them where their registers are first used).
+#ifndef UAVTRACK_T3_KO   // timing experiments on pmi_score_t3_kernel only (results are wrong): bit 0 no tile barrier, 1 no producer
+#define UAVTRACK_T3_KO 0  // items, 2 no epilogue items, 3 no B-fragment reads past the first, 5 fragment reads issued but not consumed (no waits)
+#endif
+#ifndef UAVTRACK_T3_BARRIER_BACK   // MFMAs of a tile that run behind its barrier (1 .. 8; 0: the per-width default)
+#define UAVTRACK_T3_BARRIER_BACK 0
+#endif
+#ifndef UAVTRACK_T3_RING           // B-fragment ring of pmi_score_t3_kernel: slots, and k-steps a request runs ahead of its use
+#define UAVTRACK_T3_RING 3
+#endif
+#ifndef UAVTRACK_T3_AHEAD
+#define UAVTRACK_T3_AHEAD 2
+#endif
+#ifndef UAVTRACK_T3_STAMPS   // timing experiment: s_memtime stamps inside the tile loop of workgroup 0, printed by launch_pmi_score
+#define UAVTRACK_T3_STAMPS 0
+#endif
+#if UAVTRACK_T3_STAMPS
+__device__ unsigned long long t3_stamps[4][8];
+#endif
 #define UAVTRACK_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // compile-time loop: f(std::integral_constant<int, 0>) ... f(<N - 1>).  (The staged main loop below indexes register
@@ -302,9 +317,6 @@ __device__ __forceinline__ f2 fma2(f2 w, float x, f2 c) { return f2{fmaf(w.x, x,
 template <int H>
 __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams q)
 {
-    // launched behind pmi_score_t3_kernel as its wide-range stand-by: nothing to do unless that kernel met an operand
-    // beyond f16's range (uniform over the grid)
-    if (q.gate && *q.gate == 0u) return;
     constexpr int K = 3 * H;             // fc1 input width
     constexpr int KS = K / 16;           // MFMA k-steps (32x32x16)
     constexpr int PITCH = K * 2 + 16;    // bytes per activation row of one plane
@@ -426,7 +438,7 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
             constexpr int i = br == 0 ? kk : br == 1 ? 5 + kk : 9 + kk;
             const float4 &f = P.x[i / 4];
             const float xi = i % 4 == 0 ? f.x : i % 4 == 1 ? f.y : i % 4 == 2 ? f.z : f.w;
-            const f2 wgt = br == 0 ? wc[min_c(kk, 4)] : br == 1 ? wo[min_c(kk, 3)] : wb[min_c(kk, 2)];
+            const f2 wgt = br == 0 ? wc[kk] : br == 1 ? wo[kk] : wb[kk];
             const f2 bias = br == 0 ? bc : br == 1 ? bo : bb;
             P.v[br] = fma2(wgt, xi, kk == 0 ? bias : P.v[br]);
         } else if constexpr (op < 15) {
@@ -598,14 +610,25 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_x6_kernel(const PmiParams 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// f16 helpers of pmi_score_t3_kernel.  f16 keeps 11 significant bits, so an fp32 value is a two-term sum to 2^-22:
+// pmi_score_h3_kernel<H>: the same weight-stationary scorer on the F16 matrix cores -- THREE MFMAs per fp32 product
+// instead of six, at the same accuracy.  f16 keeps 11 significant bits, so an fp32 value is a two-term sum to 2^-22:
 //     x = xh + xl * 2^-11,   xh = f16(x),  xl = f16((x - xh) * 2^11)       (the remainder is exact in fp32; scaled so
-// that it stays a NORMAL f16 number whatever the magnitude of x), and x * w = xh*wh + 2^-11 (xh*wl + xl*wh) + O(2^-22 |x w|):
-// THREE v_mfma_f32_32x32x16_f16 per fp32 product (exact products, fp32 accumulation) where the bf16 split needs six.
+// that it stays a NORMAL f16 number whatever the magnitude of x -- an unscaled remainder of a weight of 0.05 would sit
+// in the subnormal range and keep four bits), and
+//     x * w = xh*wh + 2^-11 (xh*wl + xl*wh) + O(2^-22 |x w|)
+// -- v_mfma_f32_32x32x16_f16 (the bf16 form's rate): products exact, fp32 accumulate, the two orders of magnitude in TWO
+// accumulators that are combined once per tile (acc_hi + 2^-11 acc_lo).  Emulated in numpy against fp64 (tests/
+// test_host_cpu.py) its error is that of the bf16 x 6 scheme and of an fp32 fmaf chain -- the fp32 accumulation, not the
+// split, sets it -- and the GPU tests hold it to the same bounds.  f16's range is the one thing bf16 did not have to
+// think about: operands beyond 65504 would saturate, so uavtrack_set_pmi_weights bounds the weights and the branch
+// activations (from the observation ranges) on the host and keeps the bf16 x 6 kernel for networks that could get there.
+// Everything else -- stationary planes in the accumulation-register file, producer atoms dealt behind the MFMAs,
+// LDS-only tile barrier, pipelined pair gather, epilogue under the next tile -- is pmi_score_x6_kernel's; with half
+// the MFMAs per tile the kernel is now bound by the producer's VALU work, not by the matrix pipe.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f16x8 as_f16x8(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
-constexpr float kLoScale = 2048.0f;
+constexpr float kH3LoScale = 2048.0f, kH3LoInv = 1.0f / 2048.0f;
 // two floats -> one 32-bit word of two f16 (.x in the low half), round toward zero: ONE instruction for the pair; the
 // remainder below is taken against the value that was really stored, so the rounding mode does not enter the result
 __device__ __forceinline__ unsigned pk_f16(f2 v) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v.x, v.y)); }
@@ -632,6 +655,259 @@ __device__ __forceinline__ unsigned rem_h2(unsigned hi, float a0, float a1)
     return r;
 }
 
+template <int H>
+__global__ void __launch_bounds__(H * 2, 1) pmi_score_h3_kernel(const PmiParams q)
+{
+    constexpr int K = 3 * H;             // fc1 input width
+    constexpr int KS = K / 16;           // MFMA k-steps (32x32x16)
+    constexpr int PITCH = K * 2 + 16;    // bytes per activation row of one plane
+    constexpr int PLANE = 32 * PITCH;    // bytes per plane of a tile
+    constexpr int NP = 2;                // planes: hi, lo * 2^11
+    constexpr int NW = H / 32;           // wavefronts = column blocks
+    constexpr int NT = NW * 64;          // threads = 2 H
+    constexpr int OP = H / 2;            // adjacent-output pairs per branch
+    constexpr int PG = NT / OP;          // pair groups (4)
+    constexpr int PPT = 32 / PG;         // pairs per thread in the branch layers (8)
+    static_assert(KS >= PPT, "every produced pair needs at least one k-step to hide behind");
+
+    __shared__ float4 lds4[(2 * NP * PLANE + (2 * 32 * 12 + 2 * NW * 64 + NW * 96) * 4) / 16 + 2];
+    static_assert(H != 64 || 2 * sizeof(lds4) <= 160 * 1024, "two H = 64 workgroups no longer share a CU");
+    unsigned char *aplanes = reinterpret_cast<unsigned char *>(lds4);               // [2 tiles][2 planes][32 pairs][PITCH]
+    float *xs = reinterpret_cast<float *>(aplanes + 2 * NP * PLANE);               // [2 tiles][32 pairs][12]
+    float *part = xs + 2 * 32 * 12;                                                // [2 tiles][NW][2 column halves][32]
+    float *sink = part + 2 * NW * 64;                                              // [NW][96] where non-writer lanes' stores go
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int col = w * 32 + (lane & 31);
+    const int kh = lane >> 5;
+
+    // ---- stationary operands: the two f16 planes of fc1's slice, in MFMA B-operand order (pack_pmi_h3), both parked
+    //      in the accumulation-register file for the lifetime of the workgroup (192 of its 256 registers at H = 128)
+    const float *W1 = q.blob + 15 * H;
+    const float *b1 = W1 + (size_t)K * H;
+    const float *w2 = b1 + H;
+    const float b2 = w2[H];
+    u32x4 Bh[KS], Bl[KS];
+    {
+        const u32x4 *bp = reinterpret_cast<const u32x4 *>(q.h3) + (size_t)w * NP * KS * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            Bh[s] = bp[(0 * KS + s) * 64];
+            Bl[s] = bp[(1 * KS + s) * 64];
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { asm volatile("" : "+a"(Bh[s])); asm volatile("" : "+a"(Bl[s])); }
+    }
+    const float bias1 = b1[col], wout = w2[col];
+    f32x16 biasv;                            // fc1's bias as the first hi-order MFMA's srcC
+#pragma unroll
+    for (int r = 0; r < 16; ++r) biasv[r] = bias1;
+
+    // Branch layers (PMINet.py:50-55): thread (o2, pg) owns outputs 2 o2 and 2 o2 + 1 of each of the three branches
+    // for PPT of the tile's 32 pairs; its 30 folded weights and 6 biases stay in registers.
+    const int o2 = tid % OP, pg = tid / OP;
+    f2 wc[5], wo[4], wb[3], bc, bo, bb;
+    {
+        const int o = 2 * o2;
+#pragma unroll
+        for (int v = 0; v < 5; ++v) wc[v] = f2{q.blob[v * H + o], q.blob[v * H + o + 1]};
+        bc = f2{q.blob[5 * H + o], q.blob[5 * H + o + 1]};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) wo[v] = f2{q.blob[6 * H + v * H + o], q.blob[6 * H + v * H + o + 1]};
+        bo = f2{q.blob[10 * H + o], q.blob[10 * H + o + 1]};
+#pragma unroll
+        for (int v = 0; v < 3; ++v) wb[v] = f2{q.blob[11 * H + v * H + o], q.blob[11 * H + v * H + o + 1]};
+        bb = f2{q.blob[14 * H + o], q.blob[14 * H + o + 1]};
+    }
+    const int arow0 = (pg * PPT) * PITCH + 4 * o2;
+    const int afrag0 = (lane & 31) * PITCH + kh * 16;
+
+    const unsigned npairs = *q.pair_count;
+    const unsigned ntiles = (npairs + 31) >> 5;
+    const unsigned G = gridDim.x;
+
+    // input pipeline of pmi_score_x6_kernel: pair record three tiles ahead, its observations two
+    auto load_rec = [&](unsigned tile, uint2 &pr, bool &ok) {
+        const unsigned pi = tile * 32 + tid;
+        ok = tid < 32 && tile < ntiles && pi < npairs;
+        pr = make_uint2(0, 0);
+        if (ok) pr = q.pairs[pi];
+    };
+    auto load_obs = [&](uint2 pr, bool ok, float4 (&a)[3], float4 (&b)[3]) {
+        a[0] = a[1] = a[2] = b[0] = b[1] = b[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && pr.x != 0xFFFFFFFFu) {     // (tested HERE, where the record is needed anyway: 0xFFFFFFFF = a dummy of the rollout kernel's slot pool)
+            const unsigned gi = pr.x, gj = pr.y;
+            const float4 *oi = reinterpret_cast<const float4 *>(q.obs + (size_t)gi * 12);
+            const float4 *oj = reinterpret_cast<const float4 *>(q.obs + (size_t)gj * 12);
+#pragma unroll
+            for (int v = 0; v < 3; ++v) { a[v] = oi[v]; b[v] = oj[v]; }
+        }
+    };
+    auto stash = [&](int buf, const float4 (&a)[3], const float4 (&b)[3]) {
+        if (tid < 32) {
+            float4 *dst = reinterpret_cast<float4 *>(xs + buf * 32 * 12 + tid * 12);
+#pragma unroll
+            for (int v = 0; v < 3; ++v) dst[v] = make_float4(a[v].x * b[v].x, a[v].y * b[v].y, a[v].z * b[v].z, a[v].w * b[v].w);
+        }
+    };
+    // One pair of the branch layers as kMicro atoms of one or two instructions: 12 FMA pairs, 3 ReLU pairs, and per
+    // branch the two-term f16 split -- pack (one v_cvt_pkrtz for the pair), store, convert back, exact remainder, scale,
+    // pack, store -- the three branches taking turns so that no atom waits for the one just before it.
+    constexpr int kMicro = 36, kLoadAtom = 20;
+    struct Prod { float4 x[3]; f2 v[3], hi[3]; unsigned pk[3]; };
+    auto load_x = [&](int xbuf, int pp, Prod &P) {
+        const float4 *xp = reinterpret_cast<const float4 *>(xs + xbuf * 32 * 12 + (pg * PPT + pp) * 12);
+        P.x[0] = xp[0]; P.x[1] = xp[1]; P.x[2] = xp[2];
+    };
+    auto micro = [&](Prod &P, auto opc, int xbuf, int abuf, int pp) {
+        constexpr int op = decltype(opc)::value;
+        unsigned char *dst = aplanes + abuf * NP * PLANE + arow0 + pp * PITCH;
+        if constexpr (op < 12) {
+            constexpr int br = op < 9 ? op % 3 : op < 11 ? op - 9 : 0;          // c o b  c o b  c o b  c o  c
+            constexpr int kk = op < 9 ? op / 3 : op < 11 ? 3 : 4;               // position inside the branch's chain
+            constexpr int i = br == 0 ? kk : br == 1 ? 5 + kk : 9 + kk;
+            const float4 &f = P.x[i / 4];
+            const float xi = i % 4 == 0 ? f.x : i % 4 == 1 ? f.y : i % 4 == 2 ? f.z : f.w;
+            const f2 wgt = br == 0 ? wc[min_c(kk, 4)] : br == 1 ? wo[min_c(kk, 3)] : wb[min_c(kk, 2)];
+            const f2 bias = br == 0 ? bc : br == 1 ? bo : bb;
+            P.v[br] = fma2(wgt, xi, kk == 0 ? bias : P.v[br]);
+        } else if constexpr (op < 15) {
+            P.v[op - 12] = relu2(P.v[op - 12]);
+        } else {
+            constexpr int qq = op - 15, step = qq / 3, br = qq % 3;
+            if constexpr (step == 0) P.pk[br] = pk_f16(P.v[br]);
+            else if constexpr (step == 1) *reinterpret_cast<unsigned *>(dst + br * 2 * H) = P.pk[br];
+            else if constexpr (step == 2) P.hi[br] = unpk_f16(P.pk[br]);
+            else if constexpr (step == 3) P.v[br] = sub2(P.v[br], P.hi[br]);
+            else if constexpr (step == 4) P.v[br] = scale2(P.v[br], kH3LoScale);
+            else if constexpr (step == 5) P.pk[br] = pk_f16(P.v[br]);
+            else *reinterpret_cast<unsigned *>(dst + PLANE + br * 2 * H) = P.pk[br];
+        }
+        if constexpr (op == kLoadAtom) { if (pp + 1 < PPT) load_x(xbuf, pp + 1, P); }
+    };
+    auto produce_pair = [&](Prod &P, int xbuf, int abuf, int pp) {       // all of it at once (prologue)
+        static_for<kMicro>([&](auto opc) { micro(P, opc, xbuf, abuf, pp); });
+    };
+
+    // ---- prologue
+    uint2 rec_n;
+    bool rec_ok;
+    float4 oa[3], ob[3];
+    {
+        load_rec(blockIdx.x, rec_n, rec_ok);
+        load_obs(rec_n, rec_ok, oa, ob);
+        stash(0, oa, ob);
+        load_rec(blockIdx.x + G, rec_n, rec_ok);
+        load_obs(rec_n, rec_ok, oa, ob);
+        __syncthreads();
+        Prod P0;
+        load_x(0, 0, P0);
+#pragma unroll 2
+        for (int pp = 0; pp < PPT; ++pp) produce_pair(P0, 0, 0, pp);
+        stash(1, oa, ob);
+        load_rec(blockIdx.x + 2 * G, rec_n, rec_ok);
+        load_obs(rec_n, rec_ok, oa, ob);
+        load_rec(blockIdx.x + 3 * G, rec_n, rec_ok);
+        __syncthreads();
+    }
+
+    // ReLU, fc2 (PMINet.py:60-61) of a finished tile: as in pmi_score_x6_kernel, with the two orders combined first
+    auto epi_piece = [&](const f32x16 &ah, const f32x16 &al, float (&ev)[2], auto ec, float *pc) {
+        constexpr int e = decltype(ec)::value, st = e % 6;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = 2 * (e / 6) + u;
+            if constexpr (st == 0) ev[u] = __int_as_float(max(__float_as_int(fmaf(al[r], kH3LoInv, ah[r])), 0)) * wout;
+            else if constexpr (st == 1) ev[u] = dpp_add<0xB1>(ev[u]);
+            else if constexpr (st == 2) ev[u] = dpp_add<0x4E>(ev[u]);
+            else if constexpr (st == 3) ev[u] = dpp_add<0x141>(ev[u]);
+            else if constexpr (st == 4) ev[u] = dpp_add<0x140>(ev[u]);
+            else pc[(r & 3) + 8 * (r >> 2)] = ev[u];
+        }
+    };
+    auto partial_base = [&](int buf) {       // writer: lane 0 of each 16-lane row
+        return (lane & 15) == 0 ? part + buf * NW * 64 + w * 64 + ((lane >> 4) & 1) * 32 + 4 * kh : sink + w * 96 + lane;
+    };
+    const int ft = tid - (NW - 1) * 64;
+    auto final_sum = [&](unsigned tile, const float *pc) {      // over the column blocks, in order
+        if (ft >= 0 && ft < 32 && tile * 32 + ft < npairs) {
+            float sc = b2;
+#pragma unroll
+            for (int ww = 0; ww < 2 * NW; ++ww) sc += pc[ww * 32 + ft];
+            q.scores[tile * 32 + ft] = sc;
+        }
+    };
+
+    int cur = 0;
+    bool have_prev = false;
+    f32x16 accph, accpl;                     // the previous tile's accumulators: their epilogue runs under this tile's MFMAs
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accph[r] = 0.0f; accpl[r] = 0.0f; }
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += G) {
+        f32x16 acch = biasv, accl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accl[r] = 0.0f;
+        const unsigned char *afrag = aplanes + cur * NP * PLANE + afrag0;
+        auto load_a = [&](int s, u32x4 &h, u32x4 &l) {
+            h = *reinterpret_cast<const u32x4 *>(afrag + 0 * PLANE + s * 32);
+            l = *reinterpret_cast<const u32x4 *>(afrag + 1 * PLANE + s * 32);
+        };
+        Prod P;
+        load_x(cur ^ 1, 0, P);
+        float ev[2] = {0.0f, 0.0f};
+        float *pcp = partial_base(cur ^ 1);
+        u32x4 fh, fl, gh, gl;                 // this k-step's fragments, the next one's
+        load_a(0, fh, fl);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<KS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            constexpr int pp = s * PPT / KS;
+            constexpr int s0 = (pp * KS + PPT - 1) / PPT, s1 = ((pp + 1) * KS + PPT - 1) / PPT;   // first k-step of pp, of pp + 1
+            constexpr int nslot = 3 * (s1 - s0);
+            static_for<3>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int slot = 3 * (s - s0) + t;
+                constexpr int lo = slot * kMicro / nslot, hi = (slot + 1) * kMicro / nslot;
+                // small terms first: lo += Ah Bl, lo += Al Bh, hi += Ah Bh -- two accumulation chains
+                const f16x8 a = as_f16x8(t == 1 ? fl : fh);
+                const f16x8 bq = as_f16x8(t == 0 ? Bl[s] : Bh[s]);
+                if constexpr (t == 2) acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, acch, 0, 0, 0);
+                else accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, accl, 0, 0, 0);
+                if constexpr (t == 0 && s + 1 < KS) load_a(s + 1, gh, gl);
+                static_for<kMicro>([&](auto opc) {
+                    if constexpr (decltype(opc)::value >= lo && decltype(opc)::value < hi) micro(P, opc, cur ^ 1, cur ^ 1, pp);
+                });
+                constexpr int gslot = 3 * s + t;
+                constexpr int elo = gslot * 48 / (3 * KS), ehi = (gslot + 1) * 48 / (3 * KS);
+                static_for<48>([&](auto ec) {
+                    if constexpr (decltype(ec)::value >= elo && decltype(ec)::value < ehi) epi_piece(accph, accpl, ev, ec, pcp);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            fh = gh; fl = gl;
+        });
+
+        stash(cur, oa, ob);                                   // x of tile + 2 G (observations requested an iteration ago)
+        load_obs(rec_n, rec_ok, oa, ob);                      // tile + 3 G (record requested an iteration ago)
+        load_rec(tile + 4 * G, rec_n, rec_ok);
+        UAVTRACK_LDS_BARRIER();
+        if (have_prev) final_sum(tile - G, part + (cur ^ 1) * NW * 64);
+        accph = acch; accpl = accl;
+        have_prev = true;
+        cur ^= 1;
+    }
+    if (have_prev) {                         // the last tile's epilogue has nothing left to hide behind
+        float ev[2] = {0.0f, 0.0f};
+        float *pcp = partial_base(cur ^ 1);
+        static_for<48>([&](auto ec) { epi_piece(accph, accpl, ev, ec, pcp); });
+        __syncthreads();
+        const unsigned last = blockIdx.x + ((ntiles - 1 - blockIdx.x) / G) * G;
+        final_sum(last, part + (cur ^ 1) * NW * 64);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // pmi_score_t3_kernel<H>: the f16 x 3 scorer with the PAIRS ON THE LANES (every product transposed).  In the two kernels
 // above a wavefront's VALU work beside the MFMAs -- branch layers, ReLU, operand split, DPP reductions -- outweighs the
@@ -642,7 +918,7 @@ __device__ __forceinline__ unsigned rem_h2(unsigned hi, float a0, float a1)
 //   * a 32x32 accumulator tile holds, per lane, 16 rows of ONE column: with the pairs as columns a lane owns 16 hidden
 //     units of its pair in groups of four adjacent ones, so ReLU and the f16 split stay in the lane and leave as two
 //     ds_write_b64 per group into the activation planes (row = pair, unit index contiguous) -- the layout layer 2 reads;
-//   * layer 2 (3H -> H) is the same MFMA with the operands swapped (weights as A, packed by pack_pmi_t3;
+//   * layer 2 (3H -> H) is the same MFMA with the operands swapped (weights as A: the very fragments pack_pmi_h3 builds;
 //     activations as B: the very LDS addresses the A fragments came from), which leaves H2^T in the accumulators: fc2
 //     (PMINet.py:61) is then 16 FMAs down the lane's registers, no cross-lane reduction at all -- the two halves of a
 //     wavefront and the column blocks are added by the thread that stores the score, as before.
@@ -651,7 +927,7 @@ __device__ __forceinline__ unsigned rem_h2(unsigned hi, float a0, float a1)
 // the activations: combine two accumulators, ReLU, pack, unpack, subtract, scale, pack = 6 per value.  Block scaling
 // removes the multiplications: the host folds a power of two S1 into the branch layers and T into fc1 (both exact)
 // such that S1 * activation bound and T * max |w| sit just inside f16's range; a value of that size has a remainder
-// x - f16(x) that is a NORMAL f16 number as it stands (an unscaled remainder would need a 2^11 factor to stay normal), for every value
+// x - f16(x) that is a NORMAL f16 number as it stands (what the 2^11 factor of the h3 kernel was for), for every value
 // above 2^-18 of the bound -- smaller ones lose remainder bits, an absolute error below 2^-25 of the bound's scale, far
 // under the fp32 rounding of the sums they enter (emulated in numpy against fp64: tests/test_host_cpu.py).  Then
 //   hi = f16(acc) (toward zero), ReLU on the packed pair, lo = f16(acc - hi) by ONE mixed-precision FMA per value
@@ -669,13 +945,13 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
     constexpr int NP = 2;                // planes: hi, lo * 2^11
     constexpr int NW = H / 32;           // wavefronts = column blocks of layer 2 = unit blocks per branch of layer 1
     constexpr int XROW = 16;             // floats per row of the x staging buffer: x_0..11, 1, 0, 0, 0
-    constexpr int kDuty0 = 2, kDutyStep = 2, kDutyItems = 12;     // the twelve items of the input duty go behind MFMAs 2, 4, .. 24 of the tile
+    constexpr int kDuty0 = 2, kDutyStep = 2;     // the eleven items of the input duty go behind MFMAs 2, 4, .. 22 of the tile
     // the tile barrier stands behind this many of the tile's MFMAs (see tile_body; H = 64 -- two workgroups per CU cover each other's barrier -- measured best with 4 behind it, 128 indifferent between 2 and 8)
-    constexpr int kBarrierSlot = 3 * (3 * H / 16) - (H <= 64 ? 4 : 6);
+    constexpr int kBarrierSlot = 3 * (3 * H / 16) - (UAVTRACK_T3_BARRIER_BACK ? UAVTRACK_T3_BARRIER_BACK : (H <= 64 ? 4 : 6));
 
     __shared__ float4 lds4[(2 * NP * PLANE + (2 * 32 * XROW + 2 * NW * 64) * 4) / 16 + 2];
     static_assert(H != 64 || 2 * sizeof(lds4) <= 160 * 1024, "two H = 64 workgroups no longer share a CU");
-    static_assert(kDuty0 + (kDutyItems - 1) * kDutyStep < kBarrierSlot && kBarrierSlot > 3 * (3 * H / 16 - 3),
+    static_assert(kDuty0 + 10 * kDutyStep < kBarrierSlot && kBarrierSlot > 3 * (3 * H / 16 - 3),
                   "LDS work behind the tile barrier / a fragment request behind it");
     unsigned char *aplanes = reinterpret_cast<unsigned char *>(lds4);               // [2 tiles][2 planes][32 pairs][PITCH]
     float *xs = reinterpret_cast<float *>(aplanes + 2 * NP * PLANE);               // [2 tiles][32 pairs][XROW]
@@ -691,7 +967,7 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
     const float *b1 = q.blob + 15 * H + (size_t)K * H;
     const float *w2 = b1 + H;
     const float b2 = w2[H];
-    u32x4 Ah[KS], Al[KS];                 // layer 2: W1^T fragments (pack_pmi_t3)
+    u32x4 Ah[KS], Al[KS];                 // layer 2: W1^T fragments (pack_pmi_h3's B fragments serve as A of the transposed product)
     {
         const u32x4 *bp = reinterpret_cast<const u32x4 *>(q.t3) + (size_t)w * NP * KS * 64 + lane;
 #pragma unroll
@@ -749,11 +1025,6 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
     };
     auto prod4 = [](const float4 &a, const float4 &b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); };   // x = la_i * la_j (uav.py:281)
     auto xs_row = [&](int buf) { return reinterpret_cast<float4 *>(xs + buf * 32 * XROW + pr32 * XROW); };
-    // f16 range watch (see PmiParams): the largest |x| of each branch's inputs -- comm x_0..4, obs x_5..8, boundary x_9..11
-    auto max3a = [](float a, float b, float c) { return fmaxf(fmaxf(fabsf(a), fabsf(b)), fabsf(c)); };
-    auto range_raise = [&](float rc, float ro, float rb) {
-        if (fmaxf(fmaxf(rc * q.rng_inv[0], ro * q.rng_inv[1]), rb * q.rng_inv[2]) > 1.0f) *q.range_flag = 1u;
-    };
 
     // ---- the producer of one tile's activation planes, as a list of items of one or two instructions each that the main
     //      loop deals out behind its MFMAs: X (operand of layer 1 from the staged inputs), M (its nine MFMAs), P (ReLU,
@@ -809,7 +1080,7 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
             if constexpr (st == 0) P.xh[pi] = pk_f16(v);
             else if constexpr (st == 1) P.t[0] = unpk_f16(P.xh[pi]);
             else if constexpr (st == 2) P.t[0] = sub2(v, P.t[0]);
-            else if constexpr (st == 3) P.t[0] = scale2(P.t[0], kLoScale);
+            else if constexpr (st == 3) P.t[0] = scale2(P.t[0], kH3LoScale);
             else P.xl[pi] = pk_f16(P.t[0]);
         }
         else if constexpr (I < I_M1) mfma_item(P, std::integral_constant<int, 0>{}, std::integral_constant<int, I - I_M0>{});
@@ -844,9 +1115,6 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
 #pragma unroll
                 for (int v = 0; v < 3; ++v) dst[v] = prod4(oa[v], ob[v]);
                 dst[3] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);            // input 12 = 1 (the bias rides on it), 13..15 = 0: written once
-                const float4 x0 = prod4(oa[0], ob[0]), x1 = prod4(oa[1], ob[1]), x2 = prod4(oa[2], ob[2]);
-                range_raise(fmaxf(max3a(x0.x, x0.y, x0.z), fmaxf(fabsf(x0.w), fabsf(x1.x))),
-                            fmaxf(max3a(x1.y, x1.z, x1.w), fabsf(x2.x)), max3a(x2.y, x2.z, x2.w));
             }
         }
         const unsigned j0 = 2u + (unsigned)((w + NW - 2 % NW) % NW);     // this wavefront's first duty: the iteration j0 >= 2 with j0 mod NW == w
@@ -886,11 +1154,15 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
 
     int cur = 0;
     unsigned it = 0;
+#if UAVTRACK_T3_STAMPS
+    unsigned long long stsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     // One tile: layer 2 of iteration `it` into (acch, accl) -- 3 KS MFMAs, the "slots" -- and dealt behind them: the producer of
     // iteration it + 1's planes, fc2 of iteration it - 1 (accph, accpl), on the wavefront whose turn it is (DUTY) the inputs
     // of iterations it + 2 .. it + 2 + 2 NW, and on the last wavefront, behind the barrier, the final sum of iteration it - 1.
     auto tile_body = [&](auto dutyc, f32x16 &acch, f32x16 &accl, const f32x16 &accph, const f32x16 &accpl) {
         constexpr bool DUTY = decltype(dutyc)::value;
+        constexpr int nslot = 3 * KS;
         acch = biasv;
 #pragma unroll
         for (int r = 0; r < 16; ++r) accl[r] = 0.0f;
@@ -902,15 +1174,18 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
         Prod P;
         float esum = 0.0f;
         float *pcp = part + (cur ^ 1) * NW * 64 + w * 64;         // the previous tile's partial scores of this wavefront
+#if UAVTRACK_T3_STAMPS
+        unsigned long long st[6];
+        st[0] = __builtin_amdgcn_s_memtime();
+#endif
         // B fragments of k-step s >= 2 live in ring slot s % 3 and are requested TWO k-steps (six MFMAs) ahead: a wavefront's
         // LDS operations complete in order, so a read queues behind the producer's stores of all four wavefronts, and one
         // k-step of lead (~100 cycles) did not cover that.  Those of k-steps 0 and 1 (nfh, nfl) were requested right behind
         // the previous tile's barrier.
-        constexpr int RING = 3, AHEAD = 2;        // (rings of 4 and 5 slots, requests 3 or 4 k-steps ahead: all within 0.3 %)
+        constexpr int RING = UAVTRACK_T3_RING, AHEAD = UAVTRACK_T3_AHEAD;
         static_assert(AHEAD >= 2 && AHEAD < RING + 1 && AHEAD <= 4, "fragment ring");
         u32x4 fh[RING], fl[RING];
         float4 dm;                            // duty: the product row in flight
-        float drc = 0.0f, dro = 0.0f, drb = 0.0f;   // ... and the largest |x| per branch so far (f16 range watch)
         ObsAddr dA;
         float4 *const dxs = xs_row(cur);      // xs[cur] fed the producer during the previous iteration: free for iteration it + 2
         static_for<KS>([&](auto sc) {
@@ -920,45 +1195,51 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
                 constexpr int slot = 3 * s + t;
                 // S1 T H2^T += (T W1)^T (S1 H1)^T, small terms first: lo += Wl Hh, lo += Wh Hl, hi += Wh Hh
                 const f16x8 a = as_f16x8(t == 0 ? Al[s] : Ah[s]);
-                const u32x4 bh = s < 2 ? nfh[s < 2 ? s : 0] : fh[s % RING], bl = s < 2 ? nfl[s < 2 ? s : 0] : fl[s % RING];
+                const u32x4 bh = (s < 2 || (UAVTRACK_T3_KO & 32)) ? nfh[s < 2 ? s : 0] : fh[s % RING], bl = (s < 2 || (UAVTRACK_T3_KO & 32)) ? nfl[s < 2 ? s : 0] : fl[s % RING];
                 const f16x8 bq = as_f16x8(t == 1 ? bl : bh);
                 if constexpr (t == 0) asm volatile("" :: "v"(bl));      // (one counted wait per k-step, for both fragments, not two)
                 if constexpr (t == 2) acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, acch, 0, 0, 0);
                 else accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, accl, 0, 0, 0);
                 // (k-steps 2 .. AHEAD - 1 are requested at the top of the tile, the others AHEAD k-steps before their use)
-                if constexpr (t == 0 && s == 0)
+                if constexpr (t == 0 && s == 0 && (UAVTRACK_T3_KO & 8) == 0)
                     static_for<AHEAD - 2>([&](auto kc) { load_b(2 + decltype(kc)::value, fh[(2 + decltype(kc)::value) % RING], fl[(2 + decltype(kc)::value) % RING]); });
-                if constexpr (t == 0 && s + AHEAD < KS) load_b(s + AHEAD, fh[(s + AHEAD) % RING], fl[(s + AHEAD) % RING]);
+                if constexpr (t == 0 && s + AHEAD < KS && (UAVTRACK_T3_KO & 8) == 0) load_b(s + AHEAD, fh[(s + AHEAD) % RING], fl[(s + AHEAD) % RING]);
                 if constexpr (slot < kBarrierSlot) {           // everything that touches the LDS images sits in front of the barrier
                     constexpr int lo = slot * NITEM / kBarrierSlot, hi = (slot + 1) * NITEM / kBarrierSlot;
+                    if constexpr ((UAVTRACK_T3_KO & 2) == 0)
                     static_for<NITEM>([&](auto ic) {
                         if constexpr (decltype(ic)::value >= lo && decltype(ic)::value < hi) item(P, ic, cur ^ 1, cur ^ 1);
                     });
                     constexpr int elo = slot * 17 / kBarrierSlot, ehi = (slot + 1) * 17 / kBarrierSlot;
+                    if constexpr ((UAVTRACK_T3_KO & 4) == 0)
                     static_for<17>([&](auto ec) {
                         if constexpr (decltype(ec)::value >= elo && decltype(ec)::value < ehi) epi_item(accph, accpl, esum, ec, pcp);
                     });
                 }
-                if constexpr (DUTY && slot >= kDuty0 && (slot - kDuty0) % kDutyStep == 0 && (slot - kDuty0) / kDutyStep < kDutyItems) {
+                if constexpr (DUTY && slot >= kDuty0 && (slot - kDuty0) % kDutyStep == 0 && (slot - kDuty0) / kDutyStep < 11) {
                     constexpr int d = (slot - kDuty0) / kDutyStep;
                     // x of iteration it + 2 (observations requested NW iterations ago), then the observations of iteration
-                    // it + 2 + NW (record requested NW iterations ago), then the record of iteration it + 2 + 2 NW; the f16
-                    // range watch rides along
+                    // it + 2 + NW (record requested NW iterations ago), then the record of iteration it + 2 + 2 NW
                     if constexpr (d == 0 || d == 2 || d == 4) dm = prod4(oa[d / 2], ob[d / 2]);
-                    else if constexpr (d == 1) { dxs[0] = dm; drc = fmaxf(max3a(dm.x, dm.y, dm.z), fabsf(dm.w)); }
-                    else if constexpr (d == 3) { dxs[1] = dm; drc = fmaxf(drc, fabsf(dm.x)); dro = max3a(dm.y, dm.z, dm.w); }
-                    else if constexpr (d == 5) { dxs[2] = dm; dro = fmaxf(dro, fabsf(dm.x)); drb = max3a(dm.y, dm.z, dm.w); }
-                    else if constexpr (d == 11) range_raise(drc, dro, drb);
+                    else if constexpr (d == 1 || d == 3 || d == 5) dxs[d / 2] = dm;
                     else if constexpr (d == 6) dA = obs_addr(rec_n);
                     else if constexpr (d < 10) { oa[d - 7] = dA.oi[d - 7]; ob[d - 7] = dA.oj[d - 7]; }
                     else rec_n = load_rec(tile_of(it + 2 + 2 * NW));
                 }
+#if UAVTRACK_T3_STAMPS
+                if constexpr (slot == kBarrierSlot / 3 - 1) st[1] = __builtin_amdgcn_s_memtime();
+                if constexpr (slot == 2 * kBarrierSlot / 3 - 1) st[2] = __builtin_amdgcn_s_memtime();
+                if constexpr (slot == kBarrierSlot - 1) st[3] = __builtin_amdgcn_s_memtime();
+#endif
                 if constexpr (slot == kBarrierSlot - 1) {
                     // THE tile barrier, six MFMAs before the tile's end: every LDS access of the tile has been issued (the
                     // last fragment request went out at slot nslot - 9) and is complete behind the wait, so the images
                     // change hands here -- and the next tile's first two fragment pairs travel under the remaining MFMAs
                     // instead of in front of an idle matrix pipe
-                    UAVTRACK_LDS_BARRIER();
+                    if constexpr ((UAVTRACK_T3_KO & 1) == 0) UAVTRACK_LDS_BARRIER();
+#if UAVTRACK_T3_STAMPS
+                    st[4] = __builtin_amdgcn_s_memtime();
+#endif
                     const unsigned char *nb = aplanes + (cur ^ 1) * NP * PLANE + bfrag0;
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
@@ -973,7 +1254,20 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
+        if constexpr ((UAVTRACK_T3_KO & 32) != 0) {      // (keep the unconsumed fragment reads alive)
+#pragma unroll
+            for (int k = 0; k < RING; ++k) asm volatile("" :: "v"(fh[k]), "v"(fl[k]));
+        }
         ++it;
+#if UAVTRACK_T3_STAMPS
+        st[5] = __builtin_amdgcn_s_memtime();
+        if (it > 8) {                        // (steady state) per wavefront: three thirds of the slots before the barrier, the barrier, the MFMAs behind it
+#pragma unroll
+            for (int k = 0; k < 5; ++k) stsum[k] += st[k + 1] - st[k];
+            stsum[5] += 1;
+            if (DUTY) { stsum[6] += st[5] - st[0]; stsum[7] += 1; }
+        }
+#endif
         cur ^= 1;
     };
     auto run_tile = [&](f32x16 &acch, f32x16 &accl, const f32x16 &accph, const f32x16 &accpl) {
@@ -1002,6 +1296,10 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
         __syncthreads();
         if (w == NW - 1) final_sum(tile_of(it - 1), part + (cur ^ 1) * NW * 64);
     }
+#if UAVTRACK_T3_STAMPS
+    if (blockIdx.x == 0 && lane == 0 && H == 128)
+        for (int k = 0; k < 8; ++k) t3_stamps[w][k] = stsum[k];
+#endif
 }
 
 struct MixParams {
@@ -1010,7 +1308,6 @@ struct MixParams {
     float *reward;               // [S][B][N]
     float *rsum;                 // [S][B] mean over the UAVs of the final reward (nullable): what the episode sum adds up
     unsigned *pair_count;        // reset here for the next chunk's pair emission
-    unsigned *flags;             // [0] the scorer's f16 range flag, cleared here; [1] chunks the wide-range kernel re-scored so far
     int32_t SB, N, E;            // SB = S * B "virtual environments"
     float coop;
 };
@@ -1029,10 +1326,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) pmi_mix_kernel(const MixParams 
     const int e = tid / N, i = tid - e * N;
     const bool active = tid < f.E * N && e < envs_here;
     const size_t gid = (size_t)(env0 + e) * N + i;
-    if (blockIdx.x == 0 && tid == 0) {
-        *f.pair_count = 0;
-        if (f.flags[0]) { f.flags[0] = 0; f.flags[1] += 1; }
-    }
+    if (blockIdx.x == 0 && tid == 0) *f.pair_count = 0;
     if (active) {
         if (SMALL) reinterpret_cast<uint4 *>(mix_lds)[tid] = reinterpret_cast<const uint4 *>(f.nbrec)[gid];
         else
@@ -1190,7 +1484,7 @@ __global__ void __launch_bounds__(256) pmi_inference_prep_kernel(const float4 *_
     pairs[k] = make_uint2(2u * k, 2u * k + 1u);
 }
 
-// fc1 for pmi_score_t3_kernel, block-scaled -- plane 0 = f16(T w), plane 1 =
+// fc1 for pmi_score_t3_kernel: the element order of pack_pmi_h3, the values block-scaled -- plane 0 = f16(T w), plane 1 =
 // f16(T w - plane 0), T a power of two (uavtrack_set_pmi_weights).
 void pack_pmi_t3(const float *abi_blob, uint16_t *planes, int H, float T)
 {
@@ -1207,6 +1501,27 @@ void pack_pmi_t3(const float *abi_blob, uint16_t *planes, int H, float T)
                     const float v = T * W1[(size_t)row * H + w * 32 + (l & 31)];
                     const _Float16 hi = (_Float16)v;
                     const _Float16 lo = (_Float16)(v - (float)hi);
+                    uint16_t bh, bl;
+                    memcpy(&bh, &hi, 2);
+                    memcpy(&bl, &lo, 2);
+                    planes[((((size_t)w * 2 + 0) * KS + s) * 64 + l) * 8 + j] = bh;
+                    planes[((((size_t)w * 2 + 1) * KS + s) * 64 + l) * 8 + j] = bl;
+                }
+}
+
+// fc1 as two f16 planes in the B-operand order of v_mfma_f32_32x32x16_f16 (same element order as pack_pmi_x6):
+// plane 0 = f16(w) (round to nearest), plane 1 = f16((w - plane 0) * 2^11).
+void pack_pmi_h3(const float *abi_blob, uint16_t *planes, int H)
+{
+    const int K = 3 * H, KS = K / 16, NW = H / 32;
+    const float *W1 = abi_blob + (size_t)15 * H;
+    for (int w = 0; w < NW; ++w)
+        for (int s = 0; s < KS; ++s)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const float v = W1[(size_t)(16 * s + 8 * (l >> 5) + j) * H + w * 32 + (l & 31)];
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
                     uint16_t bh, bl;
                     memcpy(&bh, &hi, 2);
                     memcpy(&bl, &lo, 2);
@@ -1247,19 +1562,6 @@ void pack_pmi_l1(const float *abi_blob, uint16_t *planes, int H, float S1)
                 }
 }
 
-// behind a stand-alone scorer launch (uavtrack_pmi_inference): what the mix kernel does to the counters of a MAAC-R chunk
-__global__ void pmi_counters_reset_kernel(unsigned *pair_count, unsigned *flags)
-{
-    *pair_count = 0;
-    if (flags[0]) { flags[0] = 0; flags[1] += 1; }
-}
-
-hipError_t launch_pmi_counters_reset(const uavtrack_env *env, hipStream_t stream)
-{
-    hipLaunchKernelGGL(pmi_counters_reset_kernel, dim3(1), dim3(1), 0, stream, env->pair_count, env->pmi_flags);
-    return hipGetLastError();
-}
-
 hipError_t launch_pmi_inference_prep(const float *x, float *obs2, uint2 *pairs, unsigned n, hipStream_t stream)
 {
     hipLaunchKernelGGL(pmi_inference_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, stream,
@@ -1267,33 +1569,12 @@ hipError_t launch_pmi_inference_prep(const float *x, float *obs2, uint2 *pairs, 
     return hipGetLastError();
 }
 
-int pmi_effective_scheme(const uavtrack_env *env)
-{
-    const bool split = pmi_x6_floats(env->pmi.hidden) != 0;       // widths whose planes stay register-resident: 64, 96, 128
-    if (env->pmi_scheme != UAVTRACK_PMI_AUTO) return env->pmi_scheme;
-    return split && env->pmi.t3 ? UAVTRACK_PMI_F16X3 : split ? UAVTRACK_PMI_BF16X6 : UAVTRACK_PMI_FP32;
-}
-
-bool pmi_scheme_available(const uavtrack_env *env, int scheme)
-{
-    const bool split = pmi_x6_floats(env->pmi.hidden) != 0;
-    switch (scheme) {
-    case UAVTRACK_PMI_AUTO:   return true;
-    case UAVTRACK_PMI_F16X3:  return split && env->pmi.t3 != nullptr;     // (null: a weight or an activation bound beyond f16's range)
-    case UAVTRACK_PMI_BF16X6: return split;
-    case UAVTRACK_PMI_FP32:   return true;
-    default:                  return false;
-    }
-}
-
-// One scorer launch over the pair list (the scheme: pmi_effective_scheme).  All three kernels are persistent workgroups
-// grid-striding over 32-pair tiles and are built for every multiple of 32 up to kPmiMaxHidden (uavtrack_set_pmi_weights
-// pads other widths); tuned at the reference's two: 128 (configs/MAAC-R.yaml) and 64 (the class default).
 hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream_t stream, const uint2 *pairs, float *scores, int n_uav)
 {
     PmiParams q;
     q.blob = env->pmi.blob;
     q.x6 = env->pmi.x6;
+    q.h3 = env->pmi.h3;
     q.l1 = env->pmi.l1;
     q.t3 = env->pmi.t3;
     q.t3_scale = env->pmi.t3_s1 * env->pmi.t3_t;
@@ -1304,42 +1585,86 @@ hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream
     q.scores = scores ? scores : env->scores;
     q.pair_total = env->pair_total;
     q.N = n_uav > 0 ? n_uav : env->cfg.n_uav;
-    for (int k = 0; k < 3; ++k) q.rng_inv[k] = env->pmi.rng_inv[k];
-    q.range_flag = env->pmi_flags;
-    q.gate = nullptr;
-    const int cus = env->n_cus > 0 ? env->n_cus : 256;
-    // split kernels: one workgroup (H / 32 wavefronts, one per SIMD) per CU; at H = 64 a workgroup is two wavefronts and
-    // two of them share a CU
-    const int grid_split = cus * (env->pmi.hidden <= 64 ? 2 : 1);
-    const int scheme = pmi_effective_scheme(env);
-    if (!pmi_scheme_available(env, scheme)) return hipErrorInvalidValue;
-    auto launch_x6 = [&]() -> hipError_t {
+    // persistent workgroups grid-striding over 32-pair tiles, two per CU: __launch_bounds__(2H, 2) holds
+    // the kernel to 256 registers per lane (a few spills at H = 128) so that one workgroup's branch
+    // layers / epilogue overlap the other's MFMAs -- measured +12 % over one 296-register workgroup
+    // Built for every multiple of 32 up to kPmiMaxHidden (uavtrack_set_pmi_weights pads other widths); tuned at the
+    // reference's two: 128 (configs/MAAC-R.yaml) and 64 (the class default).  Past 128 the stationary slice no longer
+    // fits 256 registers and part of it lives in scratch: correct, slower.
+    // Widths up to kPmiX6MaxHidden run the layer as six bf16 MFMAs per k-step (pmi_score_x6_kernel): one persistent
+    // workgroup per CU.  UAVTRACK_PMI_FP32=1 keeps the fp32-MFMA kernel (A/B measurements, and the wider layers).
+    static const bool force_fp32 = [] { const char *s = getenv("UAVTRACK_PMI_FP32"); return s && atoi(s) != 0; }();
+    // UAVTRACK_PMI_SCHEME = h3 | x6 | fp32 (A/B measurements); default: f16 x 3 where the weights allow it (see
+    // uavtrack_set_pmi_weights), else bf16 x 6, else the fp32-MFMA kernel
+    static const int scheme = [] {
+        const char *s = getenv("UAVTRACK_PMI_SCHEME");
+        return !s ? 0 : !strcmp(s, "h3") ? 1 : !strcmp(s, "x6") ? 2 : !strcmp(s, "fp32") ? 3 : !strcmp(s, "t3") ? 4 : 0;
+    }();
+    if (q.t3 && q.l1 && !force_fp32 && (scheme == 0 || scheme == 4)) {
+        static const int mult64t = [] {
+            const char *e = getenv("UAVTRACK_T3_GRID64");
+            const int v = e ? atoi(e) : 2;
+            return v < 1 ? 1 : (v > 4 ? 4 : v);
+        }();
+        const int gridt = (env->n_cus > 0 ? env->n_cus : 256) * (env->pmi.hidden <= 64 ? mult64t : 1);
         switch (env->pmi.hidden) {
-#define UAVTRACK_PMI_CASE(HH) case HH: hipLaunchKernelGGL(pmi_score_x6_kernel<HH>, dim3(grid_split), dim3(2 * HH), 0, stream, q); break;
+#define UAVTRACK_PMI_CASE(HH) case HH: hipLaunchKernelGGL(pmi_score_t3_kernel<HH>, dim3(gridt), dim3(2 * HH), 0, stream, q); break;
+            UAVTRACK_PMI_CASE(64) UAVTRACK_PMI_CASE(96) UAVTRACK_PMI_CASE(128)
+#undef UAVTRACK_PMI_CASE
+        default: return hipErrorInvalidValue;
+        }
+#if UAVTRACK_T3_STAMPS
+        {
+            static int printed = 0;
+            if (printed++ % 16 == 15) {
+                unsigned long long h[4][8];
+                (void)hipStreamSynchronize(stream);
+                (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(t3_stamps), sizeof(h));
+                for (int ww = 0; ww < 4; ++ww) {
+                    const double n = (double)h[ww][5];
+                    if (n > 0) printf("t3 stamps wave %d: tiles %.0f  slots before the barrier %.0f / %.0f / %.0f  barrier %.0f  behind it %.0f  | duty tiles %.0f: %.0f per tile\n", ww, n,
+                                      h[ww][0] / n, h[ww][1] / n, h[ww][2] / n, h[ww][3] / n, h[ww][4] / n, (double)h[ww][7], h[ww][7] ? (double)h[ww][6] / h[ww][7] : 0.0);
+                }
+                fflush(stdout);
+            }
+        }
+#endif
+        return hipGetLastError();
+    }
+    if (q.h3 && !force_fp32 && (scheme == 0 || scheme == 1)) {
+        // H = 128 / 96: one workgroup per CU, one wavefront per SIMD.  H = 64: a workgroup is two wavefronts and 52 KB of LDS
+        static const int mult64h = [] {
+            const char *e = getenv("UAVTRACK_H3_GRID64");
+            const int v = e ? atoi(e) : 2;
+            return v < 1 ? 1 : (v > 4 ? 4 : v);
+        }();
+        const int grid3 = (env->n_cus > 0 ? env->n_cus : 256) * (env->pmi.hidden <= 64 ? mult64h : 1);
+        switch (env->pmi.hidden) {
+#define UAVTRACK_PMI_CASE(HH) case HH: hipLaunchKernelGGL(pmi_score_h3_kernel<HH>, dim3(grid3), dim3(2 * HH), 0, stream, q); break;
             UAVTRACK_PMI_CASE(64) UAVTRACK_PMI_CASE(96) UAVTRACK_PMI_CASE(128)
 #undef UAVTRACK_PMI_CASE
         default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
-    };
-    if (scheme == UAVTRACK_PMI_F16X3) {
+    }
+    if (q.x6 && !force_fp32 && scheme != 3) {
+        // one workgroup per CU at H = 96 / 128 (3 - 4 wavefronts, one per SIMD); at H = 64 a workgroup is two wavefronts and
+        // 81 KB of LDS, so two of them share a CU and fill its four SIMDs
+        static const int mult64 = [] {
+            const char *e = getenv("UAVTRACK_X6_GRID64");
+            const int v = e ? atoi(e) : 2;
+            return v < 1 ? 1 : (v > 4 ? 4 : v);          // (experiments; anything unparsable or out of range is clamped)
+        }();
+        const int grid6 = (env->n_cus > 0 ? env->n_cus : 256) * (env->pmi.hidden <= 64 ? mult64 : 1);
         switch (env->pmi.hidden) {
-#define UAVTRACK_PMI_CASE(HH) case HH: hipLaunchKernelGGL(pmi_score_t3_kernel<HH>, dim3(grid_split), dim3(2 * HH), 0, stream, q); break;
+#define UAVTRACK_PMI_CASE(HH) case HH: hipLaunchKernelGGL(pmi_score_x6_kernel<HH>, dim3(grid6), dim3(2 * HH), 0, stream, q); break;
             UAVTRACK_PMI_CASE(64) UAVTRACK_PMI_CASE(96) UAVTRACK_PMI_CASE(128)
 #undef UAVTRACK_PMI_CASE
         default: return hipErrorInvalidValue;
         }
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        // The stand-by: the host-side range guard of uavtrack_set_pmi_weights is built on nominal observation ranges, and the
-        // uav.py:165 weight 1 / min(d, 1) is unbounded next to the origin.  The f16 kernel watches its inputs; when a tile
-        // could saturate an operand it raises a flag and the bf16 x 6 kernel (fp32's exponent range) scores the chunk
-        // again, stream-ordered, no host round trip.  With the flag down this launch returns at once (~3 us).
-        q.gate = env->pmi_flags;
-        return launch_x6();
+        return hipGetLastError();
     }
-    if (scheme == UAVTRACK_PMI_BF16X6) return launch_x6();
-    const int grid = 512;            // fp32 MFMA, two workgroups per CU (__launch_bounds__(2H, 2))
+    const int grid = 512;
     switch (env->pmi.hidden) {
 #define UAVTRACK_PMI_CASE(HH) case HH: hipLaunchKernelGGL(pmi_score_kernel<HH>, dim3(grid), dim3(2 * HH), 0, stream, q); break;
         UAVTRACK_PMI_CASE(32) UAVTRACK_PMI_CASE(64) UAVTRACK_PMI_CASE(96) UAVTRACK_PMI_CASE(128)
@@ -1356,11 +1681,11 @@ hipError_t launch_pmi_finalize(const uavtrack_env *env, int steps, float *reward
     MixParams f;
     f.nbrec = env->nbrec; f.scores = env->scores; f.reward = reward; f.rsum = rsum;
     f.pair_count = env->pair_count;
-    f.flags = env->pmi_flags;
     // one lane per UAV-step (the rollout kernel's geometry is its own)
+    static const int mix_wgs = [] { const char *e = getenv("UAVTRACK_MIX_WGS"); const int v = e ? atoi(e) : 0; return (v == 64 || v == 128 || v == 256 || v == 512) ? v : 0; }();
     // single-wavefront groups where whole instances fill >= 90 % of a wavefront (measured 0.141 vs 0.150 ms per 200 steps at 4096 x 20)
     const int dflt = (c.n_uav <= 64 && (64 / c.n_uav) * c.n_uav * 10 >= 64 * 9) ? 64 : (c.n_uav <= 256 ? 256 : kMaxWorkgroup);
-    const int wgs = dflt;
+    const int wgs = (mix_wgs && c.n_uav <= mix_wgs) ? mix_wgs : dflt;
     f.SB = steps * c.n_envs; f.N = c.n_uav; f.E = wgs / c.n_uav;
     f.coop = env->base.coop;
     const unsigned groups = (unsigned)((f.SB + f.E - 1) / f.E);

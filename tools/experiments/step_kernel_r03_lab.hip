@@ -42,8 +42,37 @@
 
 // Partial unrolling of the pair sweeps (in agent pairs): full unrolling lets the scheduler
 // hoist every LDS table read of the environment into registers (256 VGPRs + scratch).
+#ifndef UAVTRACK_UNROLL_U
 #define UAVTRACK_UNROLL_U 5
+#endif
+// Peer rows the sweeps' LDS reads run ahead of their use in the lone-wavefront (small-grid) kernel variant
+#ifndef UAVTRACK_LDS_PREFETCH
+#define UAVTRACK_LDS_PREFETCH 2
+#endif
+#ifndef UAVTRACK_LDS_PREFETCH_PMI   // ... in its MAAC-R form (more live state: neighbour masks, the slot pool)
+#define UAVTRACK_LDS_PREFETCH_PMI 0   // (measured: 0.709 ms per 200 steps against 0.779 / 0.785 with depth 1 / 2, which spill)
+#endif
+#ifndef UAVTRACK_BRANCHFREE
+#define UAVTRACK_BRANCHFREE 1
+#endif
+#ifndef UAVTRACK_UNROLL_T
 #define UAVTRACK_UNROLL_T 5
+#endif
+#ifndef UAVTRACK_FULL_BARRIER      // 0: the two step barriers order LDS only (s_waitcnt lgkmcnt(0); s_barrier) -- measured neutral
+#define UAVTRACK_FULL_BARRIER 1
+#endif
+#ifndef UAVTRACK_SYM_DUP           // 0: every lane sweeps all peers for the duplicate term (A/B measurements)
+#define UAVTRACK_SYM_DUP 1
+#endif
+#ifndef UAVTRACK_REG_TARGETS_50
+#define UAVTRACK_REG_TARGETS_50 0
+#endif
+#ifndef UAVTRACK_KNOCKOUT_COVERAGE // timing experiment only: 1 drops the coverage atomics (covered counts read 0)
+#define UAVTRACK_KNOCKOUT_COVERAGE 0
+#endif
+#ifndef UAVTRACK_KNOCKOUT_BARRIER  // timing experiments only (results are racy): 1 drops the second step barrier, 2 both
+#define UAVTRACK_KNOCKOUT_BARRIER 0
+#endif
 
 namespace uavtrack {
 
@@ -73,6 +102,13 @@ __device__ __forceinline__ v2f splat(float v) { return (v2f){v, v}; }
 // ulp(K) * S >= 1 and clamps to exactly 1; overflow gives -inf -> 0; NaN clamps to 0 (DX10 clamp),
 // the same as the compare it replaces.  There is no packed compare/select, so this replaces
 // 2 v_cmp + 2 v_cndmask.
+#ifndef UAVTRACK_LE_ASM
+#define UAVTRACK_LE_ASM 1
+#endif
+
+#ifndef UAVTRACK_VCONST            // 1: the single-wavefront kernel variants keep the step loop's float constants in VECTOR registers
+#define UAVTRACK_VCONST 2          // (they have hundreds to spare and run out of scalar ones: see rollout_kernel; 1: the sweeps' constants only)
+#endif
 // a wave-uniform value parked in a vector register (opaque to the compiler: it stays there)
 __device__ __forceinline__ float vreg(float x)
 {
@@ -160,8 +196,12 @@ __device__ __forceinline__ void sincos_any(float h, float *s, float *c)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       \
             __builtin_amdgcn_wave_barrier();                             \
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
+        } else if (UAVTRACK_FULL_BARRIER) {                              \
+            __syncthreads();                                             \
         } else {                                                         \
-            __syncthreads();   /* (an LDS-only barrier, no vmcnt drain, measured the same: tools/experiments) */ \
+            /* LDS-only: __syncthreads() also drains vmcnt, i.e. every wave would wait here for its own output stores   \
+               of the previous step to land in memory -- nothing on this path is ordered through global memory */         \
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                              \
         }                                                                \
     } while (0)
 
@@ -271,7 +311,11 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
         v2f d2 = pk_fma(dy, dy, dx * dx);
         if (Z3) { const v2f dz = tzrow[kp] - zi2; d2 = pk_fma(dz, dz, d2); }
         const v2f dist = {fast_sqrt(d2.x), fast_sqrt(d2.y)};
+#if UAVTRACK_LE_ASM
         const v2f mm = pk_le_mask<VC>(d2, nscale, p.le_dp2);
+#else
+        const v2f mm = {d2.x <= p.dp2 ? 1.0f : 0.0f, d2.y <= p.dp2 ? 1.0f : 0.0f};
+#endif
         sx = pk_fma(mm, dx, sx);
         sy = pk_fma(mm, dy, sy);
         sc = pk_fma(mm, (v2f){q1.x, q1.y}, sc);
@@ -281,7 +325,7 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
         cov = pk_fma(cov, splat(4.0f), pk_le_mask<VC>(d2, nscale, p.lt_dp2));
         if (kp % kCovPairs == kCovPairs - 1 || kp == MP - 1) {       // 12 digits < 2^24: exact in fp32
             const unsigned bits = (unsigned)cov.x | ((unsigned)cov.y << 1);
-            if (bits) atomicOr(&covw[covbase + kp / kCovPairs], bits);
+            if (bits && !UAVTRACK_KNOCKOUT_COVERAGE) atomicOr(&covw[covbase + kp / kCovPairs], bits);
             cov = splat(0.f);
         }
     }
@@ -323,11 +367,17 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
             nbf = pk_fma(nbf, splat(4.0f), pk_le_mask<VC>(d2n, nscale, p.le_dp2));
         else if (NB)   // cooperative modes (N <= 64): neighbours (d <= dp on post-move poses, uav.py:278) as a bit mask
             nbmask |= ((unsigned long long)(d2n.x <= p.dp2 ? 1u : 0u) | (unsigned long long)(d2n.y <= p.dp2 ? 2u : 0u)) << (2 * jp);
+#if UAVTRACK_LE_ASM
         if (!SYM) {   // (SYM: the duplicate term is shared between the two UAVs of a pair, see sym_dup)
             const v2f w = pk_fma((v2f){fast_sqrt(d2n.x), fast_sqrt(d2n.y)}, splat(-p.exp_k1), splat(p.exp_k0));
             dup = pk_fma(pk_le_mask<VC>(d2n, nscale, p.le_two_dp2), (v2f){fast_exp2(w.x), fast_exp2(w.y)}, dup);
         }
         const v2f mm = pk_le_mask<VC>(d2m, nscale, p.le_dc2);
+#else
+        const v2f w = pk_fma((v2f){fast_sqrt(d2n.x), fast_sqrt(d2n.y)}, splat(-p.exp_k1), splat(p.exp_k0));
+        dup += (v2f){d2n.x <= p.two_dp2 ? fast_exp2(w.x) : 0.0f, d2n.y <= p.two_dp2 ? fast_exp2(w.y) : 0.0f};
+        const v2f mm = {d2m.x <= p.dc2 ? 1.0f : 0.0f, d2m.y <= p.dc2 ? 1.0f : 0.0f};
+#endif
         sx = pk_fma(mm, dxm, sx);
         sy = pk_fma(mm, dym, sy);
         sc = pk_fma(mm, (v2f){m1.x, m1.y}, sc);
@@ -495,26 +545,45 @@ __device__ __forceinline__ void sweep_weighted(const StepParams &p, int N, int M
 // EXTRAS: the launch uses the rarely wanted per-step extras (target trace, automatic reset); compiled out otherwise --
 // their tests and parameters cost the plain rollout ~10 % when they sat in the same instantiation.
 // LONE: built for single-wavefront workgroups on a grid of at most a few waves per SIMD (plan_geometry's small grid).
+// (experiments only: -DUAVTRACK_WAVES_PER_EU=n asks the register allocator for n resident waves per SIMD)
+#ifdef UAVTRACK_WAVES_PER_EU
+#define UAVTRACK_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(UAVTRACK_WAVES_PER_EU)))
+#else
+#define UAVTRACK_OCCUPANCY_ATTR
+#endif
 template <int N_, int M_, int MODE, bool Z3, int POLICY, bool ALLOUT = false, bool EXTRAS = false, bool LONE = false>
-__global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams p_in)
+__global__ void __launch_bounds__(kMaxWorkgroup) UAVTRACK_OCCUPANCY_ATTR rollout_kernel(const StepParams p_in)
 {
     // Single-wavefront variants: a step uses ~40 float constants of StepParams beside ~20 pointers and offsets -- more than
     // the 102 scalar registers hold, so the compiler parks some in lanes of a vector register and fetches them back with a
     // v_readlane (a VALU instruction and a wait) wherever they are needed.  These variants run one or two wavefronts per
     // SIMD and use well under half of their vector registers: the constants that only ever feed per-lane arithmetic
     // move there for good.
+#ifndef UAVTRACK_VCONST_ACTOR       // 1: the sweeps' nine constants also in the single-wavefront actor variants (experiment)
+#define UAVTRACK_VCONST_ACTOR 0
+#endif
+#ifndef UAVTRACK_VCONST_MULTI       // 1: also the 4-wave variants of the planar specialised shapes (168 registers keep their three waves per SIMD)
+#define UAVTRACK_VCONST_MULTI 0
+#endif
     // (not with the actor inside: its variant goes from 156 to 190 registers -- two wavefronts per SIMD instead of three -- and
-    //  a 200-step actor rollout from 2.30 to 2.66 ms; not in the 4-wave variants: no registers to spare at their occupancy)
-    constexpr bool kVConst = LONE && POLICY != kPolicyActor;
+    //  a 200-step actor rollout from 2.30 to 2.66 ms)
+    constexpr bool kVConst = UAVTRACK_VCONST && (POLICY != kPolicyActor || UAVTRACK_VCONST_ACTOR) && (LONE || (UAVTRACK_VCONST_MULTI && !Z3 && N_ > 0 && N_ <= 20));
     StepParams p = p_in;
-    if (kVConst) {
+    if (kVConst && (!LONE || POLICY == kPolicyActor)) {       // (4-wave variants: only what the pair sweeps use, the registers that three waves per SIMD leave)
+#define UAVTRACK_V(f) p.f = vreg(p_in.f)
+        UAVTRACK_V(le_neg_scale); UAVTRACK_V(le_dp2); UAVTRACK_V(lt_dp2); UAVTRACK_V(le_dc2); UAVTRACK_V(le_two_dp2);
+        UAVTRACK_V(exp_k0); UAVTRACK_V(exp_k1); UAVTRACK_V(vratio); UAVTRACK_V(inv_dp);
+#undef UAVTRACK_V
+    } else if (kVConst) {
 #define UAVTRACK_V(f) p.f = vreg(p_in.f)
         UAVTRACK_V(inv_dp); UAVTRACK_V(inv_dc); UAVTRACK_V(dp2); UAVTRACK_V(dc2); UAVTRACK_V(dup_floor); UAVTRACK_V(inv_dup);
         UAVTRACK_V(vratio); UAVTRACK_V(inv_na_total); UAVTRACK_V(exp_k0); UAVTRACK_V(exp_k1); UAVTRACK_V(x_max); UAVTRACK_V(y_max);
         UAVTRACK_V(tt_ceil); UAVTRACK_V(inv_tt_ceil); UAVTRACK_V(alpha); UAVTRACK_V(beta); UAVTRACK_V(gamma);
         UAVTRACK_V(sym_k0); UAVTRACK_V(sym_inv); UAVTRACK_V(act_bias); UAVTRACK_V(inv_act_bias);
         UAVTRACK_V(le_neg_scale); UAVTRACK_V(le_dp2); UAVTRACK_V(lt_dp2); UAVTRACK_V(le_dc2); UAVTRACK_V(le_two_dp2);
+#if UAVTRACK_VCONST > 1
         UAVTRACK_V(dtv_u); UAVTRACK_V(dtv_t); UAVTRACK_V(turn_unit); UAVTRACK_V(inv_na); UAVTRACK_V(two_dp2); UAVTRACK_V(dp); UAVTRACK_V(coop);
+#endif
 #undef UAVTRACK_V
     }
     constexpr bool GREEDY = POLICY == kPolicyGreedy;
@@ -546,7 +615,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     unsigned *rstw = covw + 2 * E * CW + 2;              // [E] 0, or 1 + the episode number an environment is being reset to
     float *climb_l = reinterpret_cast<float *>(rstw + E); // (3-D) [2][UAVTRACK_MAX_CLIMB] cos / sin of the climb angles
     // symmetric duplicate term (MAAC reward mode, sym_dup): [E][x | y | (z) | 2 N accumulators]
-    constexpr bool kSym = MODE == UAVTRACK_REWARD_RAW;
+    constexpr bool kSym = UAVTRACK_SYM_DUP && MODE == UAVTRACK_REWARD_RAW;
     float *symbase = climb_l + (Z3 ? 2 * UAVTRACK_MAX_CLIMB : 0);
     const int symlen = sym_pose_len(N), symstride = sym_words(N, Z3);
 
@@ -629,7 +698,10 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     float *const own0 = reinterpret_cast<float *>(uenv + (i >> 1) * 6) + (i & 1);
     // (register-resident targets cost five registers: at 50 x 25 that is the difference between three and four waves per
     // SIMD -- 16.6 vs 17.4 G agent-steps/s at 8192 envs in 3-D -- so the larger shapes keep the LDS read-modify-write)
-    constexpr bool kRegTargets = LONE || (N_ > 0 && N_ <= 20);
+    // (... except in the plain rollout variant -- pre-sampled actions, every output, no extras, MAAC reward -- which has the
+    // five registers to spare at 128: 4.11-4.15 against 4.19-4.21 ms per 200 steps at 8192 x 50 x 25)
+    constexpr bool kRegTargets = LONE || (N_ > 0 && N_ <= 20) ||
+                                 (UAVTRACK_REG_TARGETS_50 && N_ > 0 && N_ <= 50 && MODE == UAVTRACK_REWARD_RAW && ALLOUT && !EXTRAS && POLICY == kPolicyGiven);
     const bool one_target_per_lane = kRegTargets && E * M <= nthreads;
     const bool my_target = tid < envs_here * M;
     float *tgt = reinterpret_cast<float *>(ttab);
@@ -677,11 +749,15 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         }
     };
 
-    // The single-wavefront plain rollout runs even and odd steps as two copies of the loop body: the table copy that is
-    // "post-move" alternates with the step, so per copy every per-pair row address is a per-lane constant.
+#ifndef UAVTRACK_UNROLL_STEPS       // 2: the single-wavefront variants run even and odd steps as two copies of the loop body -- the table
+#define UAVTRACK_UNROLL_STEPS 2    //    copy that is "post-move" alternates, so per copy every per-pair row address is a per-lane constant (1: off)
+#endif
     // (an inner loop of constant trip count that is unrolled in full, not `#pragma unroll 2` on the step loop: a loop with
     //  convergent operations in it is not unrolled when that needs a remainder loop)
-    constexpr int kStepsPerIter = (LONE && MODE == UAVTRACK_REWARD_RAW && POLICY == kPolicyGiven && !EXTRAS) ? 2 : 1;
+#ifndef UAVTRACK_UNROLL_STEPS_PMI   // ... the MAAC-R single-wavefront variant too (experiment)
+#define UAVTRACK_UNROLL_STEPS_PMI 0
+#endif
+    constexpr int kStepsPerIter = (LONE && (MODE == UAVTRACK_REWARD_RAW || (UAVTRACK_UNROLL_STEPS_PMI && MODE == UAVTRACK_REWARD_PMI)) && POLICY == kPolicyGiven && !EXTRAS) ? UAVTRACK_UNROLL_STEPS : 1;
     constexpr int kSelPairs = (kStepsPerIter == 2 && N_ > 0) ? (N_ + 1) / 2 : 1;
     const float4 *selA[kSelPairs], *selB[kSelPairs];     // (kStepsPerIter == 2) row bases of the sequential view, post-move copy 0 / 1
     if (kStepsPerIter == 2) {
@@ -831,7 +907,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                 dq[i] = 0; dq[N + i] = 0;
             }
         }
-        UAVTRACK_STEP_BARRIER();
+        if (UAVTRACK_KNOCKOUT_BARRIER < 2) UAVTRACK_STEP_BARRIER();
 
         // ---- P2: pair sweeps
         float tt = 0, bp = 0, dupn = 0, raw = 0;
@@ -843,10 +919,6 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         constexpr bool kMask = (MODE != UAVTRACK_REWARD_RAW) && N_ > 0 && N_ <= 64;
         unsigned long long nbmask = 0;
         unsigned sym_own = 0;                       // (kSym) this lane's own half of the duplicate-term pairs, fixed point
-        // LDS reads of the sweeps run this many peer rows ahead of their use: 2 in the single-wavefront plain rollout (a lone wave
-        // has nothing else to cover an LDS round trip with); its MAAC-R and in-kernel-policy forms have more live state (neighbour
-        // masks, the slot pool, the actor's fragments) and spill with any prefetch (0.709 ms per 200 steps against 0.78)
-        constexpr int kPrefetchRows = (LONE && MODE != UAVTRACK_REWARD_PMI && POLICY == kPolicyGiven) ? 2 : 0;
         if (active) {
             Acc acc;
             // weight of uav.py:165 can be < 1 only near the origin (|rel| <= 1, so |abs| < 2 is necessary).  The branch
@@ -866,7 +938,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                         nbmask |= (unsigned long long)(d2 <= p.dp2 ? 1u : 0u) << j;
                     }
             } else {
-                sweep_fast<N_, M_, Z3, kMask, kPrefetchRows, kSym, kVConst>(p, N, M, i, rowNew, rowOld, tenv, tzrow, covw, cbuf + e * CW,
+                sweep_fast<N_, M_, Z3, kMask, LONE ? ((MODE == UAVTRACK_REWARD_PMI || POLICY != kPolicyGiven) ? UAVTRACK_LDS_PREFETCH_PMI : UAVTRACK_LDS_PREFETCH) : 0, kSym, kVConst>(p, N, M, i, rowNew, rowOld, tenv, tzrow, covw, cbuf + e * CW,
                                               x, y, z, c, s, ai, xo, yo, zo, co, so, ao, acc, nbmask,
                                               kStepsPerIter == 2 ? (tpar == 0 ? selA : selB) : nullptr);   // (pn == tpar: t0 is even)
             }
@@ -877,6 +949,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             }
 
             // ---- P3: local state (uav.py:156-190)
+#if UAVTRACK_BRANCHFREE
             {   // empty list -> -1 (uav.py:174,186): computed unconditionally, selected afterwards (0 * rcp(0) never survives)
                 const float rcU = fast_rcp(acc.cntU), rcT = fast_rcp(acc.cntT);
                 const bool anyU = acc.cntU > 0.0f, anyT = acc.cntT > 0.0f;
@@ -890,6 +963,27 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                 o[7] = anyT ? acc.scT * rcT : -1.0f;
                 o[8] = anyT ? acc.ssT * rcT : -1.0f;
             }
+#else
+            if (acc.cntU > 0.0f) {
+                const float rc = fast_rcp(acc.cntU);
+                o[0] = acc.sxU * p.inv_dc * rc;
+                o[1] = acc.syU * p.inv_dc * rc;
+                o[2] = acc.scU * rc;
+                o[3] = acc.ssU * rc;
+                o[4] = acc.saU * p.inv_na_total * rc;
+            } else {
+                o[0] = o[1] = o[2] = o[3] = o[4] = -1.0f;
+            }
+            if (acc.cntT > 0.0f) {
+                const float rc = fast_rcp(acc.cntT);
+                o[5] = acc.sxT * p.inv_dp * rc;
+                o[6] = acc.syT * p.inv_dp * rc;
+                o[7] = acc.scT * rc;
+                o[8] = acc.ssT * rc;
+            } else {
+                o[5] = o[6] = o[7] = o[8] = -1.0f;
+            }
+#endif
             o[9] = x * p.inv_dc;
             o[10] = y * p.inv_dc;
             o[11] = ai * p.inv_na_total;
@@ -897,11 +991,18 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             // ---- raw reward terms, clipped and normalised (environment.py:207-220)
             float d_bdr = fminf(fminf(x, p.x_max - x), fminf(y, p.y_max - y));
             if (Z3) d_bdr = fminf(d_bdr, fminf(z, p.z_max - z));
+#if UAVTRACK_BRANCHFREE
             // boundary punishment (uav.py:231-260) and its normalisation (environment.py:209,216), folded:
             //   d < 0: -0.5 -> -1;  0 <= d < dp: -0.5 (dp - d) / dp -> d / dp - 1;  d >= dp: 0 -> 0   ==  clamp(d / dp, 0, 1) - 1
             bp = __builtin_amdgcn_fmed3f(d_bdr * p.inv_dp, 0.0f, 1.0f) - 1.0f;
             tt = __builtin_amdgcn_fmed3f(acc.trk, 0.0f, p.tt_ceil) * p.inv_tt_ceil;
             if (!kSym) dupn = (__builtin_amdgcn_fmed3f(acc.dup * -0.5f, p.dup_floor, 0.0f) - p.dup_floor) * p.inv_dup - 1.0f;
+#else
+            float bpun = (d_bdr >= 0.0f) ? ((d_bdr < p.dp) ? -0.5f * (p.dp - d_bdr) * p.inv_dp : 0.0f) : -0.5f;
+            tt = fminf(fmaxf(acc.trk, 0.0f), p.tt_ceil) * p.inv_tt_ceil;
+            bp = (fminf(fmaxf(bpun, -0.5f), 0.0f) + 0.5f) * 2.0f - 1.0f;
+            dupn = (fminf(fmaxf(acc.dup * -0.5f, p.dup_floor), 0.0f) - p.dup_floor) * p.inv_dup - 1.0f;
+#endif
             if (!kSym) raw = p.alpha * tt + p.beta * bp + p.gamma * dupn;      // (kSym: behind the barrier, once the partners' halves are in)
             if (MODE != UAVTRACK_REWARD_RAW) rawl[e * (N + 1) + i] = raw;
         }
@@ -912,7 +1013,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             wg_cnt[0] = 0;
             if (t > 0) wg_cnt[1] = pe_base;
         }
-        UAVTRACK_STEP_BARRIER();
+        if (UAVTRACK_KNOCKOUT_BARRIER < 1) UAVTRACK_STEP_BARRIER();
 
         // ---- P4: cooperative reward, coverage, outputs
         if (active) {
@@ -1275,13 +1376,12 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     }
 }
 
-// (the symmetric duplicate term's pose arrays and accumulators exist in the MAAC reward mode only: kSym)
-size_t lds_bytes_for(int E, int N, int M, bool z3, int reward_mode)
+size_t lds_bytes_for(int E, int N, int M, bool z3)
 {
     const size_t CW = cov_words(M), MP = pairs_of(M);
     const size_t f4 = (size_t)E * ustride_of(N) + (size_t)E * tstride_of(M);
     const size_t f = (size_t)E * M + (size_t)E * (N + 1) + (z3 ? (size_t)E * MP * 2 : 0) + (size_t)E * M + 2 * E * CW + 2 + E +
-                     (z3 ? 2 * UAVTRACK_MAX_CLIMB : 0) + (reward_mode == UAVTRACK_REWARD_RAW ? (size_t)E * sym_words(N, z3) : 0);
+                     (z3 ? 2 * UAVTRACK_MAX_CLIMB : 0) + (size_t)E * sym_words(N, z3);
     return (f4 * 16 + f * 4 + 15) & ~(size_t)15;   // ustride >= 3 N float4 per env, so ep_sums staging (E N float4) fits
 }
 
@@ -1305,21 +1405,12 @@ KernelFn pick_reward(int mode, bool z3)
     }
 }
 
-// The launches a single-wavefront (LONE) kernel variant exists for: pre-sampled actions with every output, or the fused
-// actor rollout; no extras, planar, a specialised shape up to 20 x 10 (what sweep_fast's prefetch is written for).
-constexpr bool lone_shape(int n_spec, int m_spec) { return n_spec > 0 && n_spec <= 20 && m_spec <= 10; }
-bool lone_variant_exists(int N, int M, bool z3, int policy, bool allout, bool extras)
-{
-    const bool shape = (N == 20 && M == 10) || (N == 10 && M == 10) || (N == 5 && M == 3);      // the specialised shapes that pass lone_shape()
-    return shape && !z3 && !extras && ((policy == kPolicyGiven && allout) || policy == kPolicyActor);
-}
-
 // Instantiations: pre-sampled actions with every output and no extras (the learner's rollout, the benchmark);
 // any policy without extras; any policy with them.
 template <int N_, int M_>
 KernelFn pick_mode(int mode, bool z3, int policy, bool allout, bool extras, bool lone)
 {
-    if constexpr (lone_shape(N_, M_)) {
+    if constexpr (N_ > 0 && N_ <= 20 && M_ <= 10) {       // the shapes sweep_fast's prefetch is written for
         if (policy == kPolicyGiven && allout && !extras && lone && !z3)
             return pick_reward<N_, M_, kPolicyGiven, true, false, true>(mode, false);
         // the fused actor rollout on single-wavefront groups: wave fences for barriers and, under MAAC-R, pair-list slots
@@ -1339,12 +1430,18 @@ KernelFn pick_kernel(int N, int M, int mode, bool z3, int *specialised, int poli
                      bool extras = false, bool lone = false)
 {
     *specialised = 1;
+#ifdef UAVTRACK_ONLY_SHAPE_N     // experiment builds (tools/build_variant.sh): one shape only, a fraction of the compile time
+    if (N == UAVTRACK_ONLY_SHAPE_N && M == UAVTRACK_ONLY_SHAPE_M)
+        return pick_mode<UAVTRACK_ONLY_SHAPE_N, UAVTRACK_ONLY_SHAPE_M>(mode, z3, policy, allout, extras, lone);
+    return nullptr;
+#else
     if (N == 20 && M == 10) return pick_mode<20, 10>(mode, z3, policy, allout, extras, lone);
     if (N == 50 && M == 25) return pick_mode<50, 25>(mode, z3, policy, allout, extras, lone);
     if (N == 10 && M == 10) return pick_mode<10, 10>(mode, z3, policy, allout, extras, lone);
     if (N == 5 && M == 3) return pick_mode<5, 3>(mode, z3, policy, allout, extras, lone);
     *specialised = 0;
     return pick_mode<0, 0>(mode, z3, policy, allout, extras, lone);
+#endif
 }
 
 }  // namespace
@@ -1369,7 +1466,7 @@ Geometry plan_geometry(const uavtrack_config &cfg, int n_simd, bool allow_small_
     // The fused actor rollout adds 5 KB per wavefront behind the tables (actor.h): reserved here, so that every
     // geometry this function returns can also run uavtrack_run_actor.
     auto lds_need = [&](int wgs, int E) {
-        return lds_bytes_for(E, N, cfg.m_targets, cfg.dim == 3, cfg.reward_mode) + (size_t)(wgs / 64) * kActorLdsFloats * sizeof(float);
+        return lds_bytes_for(E, N, cfg.m_targets, cfg.dim == 3) + (size_t)(wgs / 64) * kActorLdsFloats * sizeof(float);
     };
     auto envs_of = [&](int wgs) {
         int E = wgs / N;
@@ -1418,7 +1515,7 @@ Geometry plan_geometry(const uavtrack_config &cfg, int n_simd, bool allow_small_
     g.wgs = best;
     g.envs_per_wg = envs_of(best);
     g.groups = (cfg.n_envs + g.envs_per_wg - 1) / g.envs_per_wg;
-    g.lds_bytes = lds_bytes_for(g.envs_per_wg, N, cfg.m_targets, cfg.dim == 3, cfg.reward_mode);
+    g.lds_bytes = lds_bytes_for(g.envs_per_wg, N, cfg.m_targets, cfg.dim == 3);
     pick_kernel(N, cfg.m_targets, cfg.reward_mode, cfg.dim == 3, &g.specialised);
     return g;
 }
@@ -1430,21 +1527,12 @@ size_t rollout_lds_bytes(const Geometry &g, int policy)
     return lds;
 }
 
-hipError_t launch_rollout(uavtrack_env *env, const StepParams &p, hipStream_t stream, int policy, const Geometry *geo)
+hipError_t launch_rollout(const uavtrack_env *env, const StepParams &p, hipStream_t stream, int policy, const Geometry *geo)
 {
     int spec = 0;
+    const Geometry &g = geo ? *geo : env->geo;
     const bool allout = p.obs && p.reward && p.terms && p.covered && p.done;
     const bool extras = p.auto_reset || p.tpos;
-    // MAAC-R: the single-wavefront geometry only pays with the kernel variant written for it (pair-list slots from a pool).
-    // Every other launch -- an output not requested, the target trace, the automatic reset -- would run the 4-wave emission
-    // path (one pair-list reservation per workgroup-step on ONE counter) on four times the workgroups: measured 15.8
-    // against 5.2 us per step at 4096 envs.  Those launches keep the 256-thread geometry.
-    if (!geo && env->cfg.reward_mode == UAVTRACK_REWARD_PMI && env->geo.lone &&
-        !lone_variant_exists(p.N, p.M, env->cfg.dim == 3, policy, allout, extras))
-        geo = &env->geo_short;
-    const Geometry &g = geo ? *geo : env->geo;
-    env->last_launch = g;
-    env->last_launch.lone = g.lone && lone_variant_exists(p.N, p.M, env->cfg.dim == 3, policy, allout, extras);
     KernelFn fn = pick_kernel(p.N, p.M, env->cfg.reward_mode, env->cfg.dim == 3, &spec, policy, allout, extras, g.lone != 0);
     StepParams q = p;
     q.E = g.envs_per_wg;
