@@ -73,6 +73,11 @@ def parse(argv=None):
     ap.add_argument("--reward", choices=["raw", "mean", "pmi"], default="raw",
                     help="raw = MAAC (configs[1]), mean = MAAC-G, pmi = MAAC-R (configs[2])")
     ap.add_argument("--pmi-hidden", type=int, default=128)
+    ap.add_argument("--pmi-scheme", choices=["auto", "f16x3", "bf16x6", "fp32"], default="auto",
+                    help="pin the MAAC-R pair scorer (uavtrack_set_pmi_scheme); auto = the fastest the weights allow")
+    ap.add_argument("--verbose", action="store_true", help="keep the per-launch arrays and the prose notes on the line")
+    ap.add_argument("--gather-transitions", type=int, default=4096,
+                    help="N > 1: transitions each rank samples per rollout for the learner-side all-gather (0 = summary gather only)")
     ap.add_argument("--rollout", type=int, default=200, help="steps per fused launch (1 = one launch per step)")
     ap.add_argument("--policy", choices=["given", "greedy", "actor"], default="given",
                     help="where actions come from: pre-sampled (the headline workload), the fused greedy baseline "
@@ -192,6 +197,7 @@ def make_env(uavtrack, args, B, device, env_offset=0):
                              horizon=ROOFLINE_T, env_offset=env_offset)
     env = uavtrack.BatchedUavEnv(cfg, device)
     if args.reward == "pmi":
+        env.set_pmi_scheme(getattr(args, "pmi_scheme", "auto"))
         env.set_pmi(synthetic_pmi_state_dict(args.pmi_hidden, 42))
     if getattr(args, "policy", "given") == "actor":
         import torch
@@ -255,9 +261,9 @@ def run_rollouts(env, actions, plan, ep_steps, out, gather=None, policy="given",
             res = env.step_many(actions[ep_steps:ep_steps + T], out=out.get(T))   # the episode's own action rows
         out[T] = res
         ep_steps += T
-        if ep_steps >= horizon:               # end of an episode: gather summaries, start the next one
+        if ep_steps >= horizon:               # end of an episode: gather summaries (and sampled transitions), start the next one
             if gather is not None:
-                gather(res["ep_sums"])
+                gather(res, None if actions is None else actions[ep_steps - T:ep_steps])
             if bound is not None:
                 bound["episode"] += 1
                 obs = bound["reset"](bound["episode"])
@@ -291,11 +297,25 @@ def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, en
     horizon = env.cfg.horizon
     actions = torch.randint(0, na_total, (horizon, B, args.n_uav), dtype=torch.int32, device=device, generator=g)
     gather = None
+    gathered_bytes = [0, 0]          # per rank: episode summaries, sampled transitions
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        # asynchronous: the collective runs on RCCL's stream from a private copy, the next rollout does not wait
-        # for it (nor for a slower rank); every handle is waited on before the clock stops
+        # asynchronous: the collectives run on RCCL's stream from private copies, the next rollout does not wait
+        # for them (nor for a slower rank); every handle is waited on before the clock stops
         pending = []
-        gather = lambda ep: pending.append(uavtrack.gather_rollout_summary_async(ep, n_envs_total=total_envs))
+        k_tr = max(0, int(getattr(args, "gather_transitions", 0)))
+        tgen = torch.Generator(device=device).manual_seed(args.seed + 1000 + env_offset)
+        first_obs = torch.full((B, args.n_uav, 12), -1.0, device=device)
+
+        def gather(res, act_rows):
+            pending.append(uavtrack.gather_rollout_summary_async(res["ep_sums"], n_envs_total=total_envs))
+            gathered_bytes[0] += res["ep_sums"].numel() * 4
+            if k_tr and res.get("obs") is not None and res["reward"].shape[0] * B * args.n_uav >= k_tr:
+                # the learner-side exchange: K sampled (state, action, reward, next_state) rows of this rollout
+                roll = dict(obs=res["obs"], reward=res["reward"], actions=res["actions"] if "actions" in res else act_rows)
+                smp = uavtrack.sample_local_transitions(first_obs, roll, k_tr, env_offset=env_offset, n_envs_total=total_envs, generator=tgen)
+                h = uavtrack.gather_transitions_async(smp)
+                pending.append(h)
+                gathered_bytes[1] += h.nbytes_per_rank
     warm_plan, pos = launch_plan(warmup, rollout, horizon, 0)
     timed_plan, _ = launch_plan(steps, rollout, horizon, pos)
     # output buffers of every launch shape exist before the clock starts (allocation is not part of a step)
@@ -314,8 +334,8 @@ def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, en
     t0 = time.perf_counter()
     launches, _ = run_rollouts(env, actions, timed_plan, pos, out, gather=gather, policy=args.policy, obs=obs0, bound=bound)
     if gather is not None:
-        summaries = [h.wait() for h in pending]
-        assert all(s.shape[0] == total_envs for s in summaries)
+        done_h = [h.wait() for h in pending]
+        assert all(s.shape[0] == total_envs for s in done_h if torch.is_tensor(s))
     torch.cuda.synchronize(device)
     wall = time.perf_counter() - t0       # this rank's K steps (and every gather it took part in) are done; the caller takes the MAX over ranks
     if gather is not None:
@@ -324,8 +344,28 @@ def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, en
     env.close()
     if warm is not None:
         warm.pop("keep")[0].close()
+    gather_info = None
+    if gather is not None:
+        # what the collectives cost on their own: blocking, back to back, outside the timed region (in it they overlap the next rollout)
+        ep = torch.zeros(B, 5, device=device)
+        def timed(fn, reps=5):
+            fn(); torch.cuda.synchronize(device); dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize(device)
+            return (time.perf_counter() - t0) * 1e3 / reps
+        gather_info = {"summary_ms": timed(lambda: uavtrack.gather_rollout_summary(ep, n_envs_total=total_envs)),
+                       "summary_bytes_per_rank": B * 5 * 4, "timed_region_bytes_per_rank": {"summaries": gathered_bytes[0], "transitions": gathered_bytes[1]}}
+        if k_tr:
+            T0 = max(set(timed_plan), key=timed_plan.count)
+            roll = dict(obs=out[T0]["obs"], reward=out[T0]["reward"], actions=actions[:T0] if "actions" not in out[T0] else out[T0]["actions"])
+            smp = uavtrack.sample_local_transitions(first_obs, roll, min(k_tr, T0 * B * args.n_uav), env_offset=env_offset, n_envs_total=total_envs, generator=tgen)
+            gather_info["transitions_ms"] = timed(lambda: uavtrack.gather_transitions(smp))
+            gather_info["transitions_bytes_per_rank"] = smp["actions"].shape[0] * 28 * 4
+            gather_info["transitions_per_rank"] = int(smp["actions"].shape[0])
     return dict(wall_s=wall, launches=launches, steps=steps, geometry=info,
-                timed_plan=timed_plan, warm_plan=warm_plan, device_warmup=warm)
+                timed_plan=timed_plan, warm_plan=warm_plan, device_warmup=warm, gather=gather_info)
 
 
 def device_warmup(uavtrack, args, B, device, warm_ms=DEVICE_WARM_MS):
@@ -399,19 +439,27 @@ def roofline_leg(uavtrack, args, B, device, T=ROOFLINE_T, launches=ROOFLINE_LAUN
     env.set_profiling(False)
     pmi_pairs = env.pmi_pairs_scored() - pairs0 if args.reward == "pmi" else 0
     info = env.kernel_info()
+    info["last_launch"] = env.launch_info()
+    pmi_info = env.pmi_info() if args.reward == "pmi" else None
     env.close()
     srt = sorted(ms)
     return dict(T=T, launches=launches, untimed=untimed, ms=ms, avg_ms=sum(ms) / len(ms), median_ms=srt[len(srt) // 2],
-                min_ms=srt[0], max_ms=srt[-1], pmi_pairs=pmi_pairs, geometry=info, kernels=kernels)
+                min_ms=srt[0], max_ms=srt[-1], pmi_pairs=pmi_pairs, geometry=info, kernels=kernels, pmi_info=pmi_info)
+
+
+VERBOSE = False     # --verbose: per-launch arrays and prose notes stay on the line (the default line is kept short: the driver
+                    # stores the tail of stdout, and what it must be able to read is in `configs` at the very end)
 
 
 def leg_summary(roof):
     """The per-launch statistics every roofline object carries."""
-    k = {name: {"ms_per_launch": v["ms"] / roof["launches"], "kernel_launches_per_launch": v["launches"] / roof["launches"]}
-         for name, v in roof["kernels"].items() if v["launches"]}
-    return {"steps_per_launch": roof["T"], "launches_timed": roof["launches"], "launches_untimed_before": roof["untimed"],
-            "avg_launch_ms": roof["avg_ms"], "median_launch_ms": roof["median_ms"], "min_launch_ms": roof["min_ms"],
-            "max_launch_ms": roof["max_ms"], "launch_ms": roof["ms"], "kernel_ms": k}
+    k = {name: round(v["ms"] / roof["launches"], 5) for name, v in roof["kernels"].items() if v["launches"]}
+    d = {"steps_per_launch": roof["T"], "launches_timed": roof["launches"], "launches_untimed_before": roof["untimed"],
+         "avg_launch_ms": roof["avg_ms"], "median_launch_ms": roof["median_ms"], "min_launch_ms": roof["min_ms"],
+         "max_launch_ms": roof["max_ms"], "kernel_ms_per_launch": k}
+    if VERBOSE:
+        d["launch_ms"] = roof["ms"]
+    return d
 
 
 def pmi_roofline(args, roof, units_per_launch):
@@ -420,12 +468,11 @@ def pmi_roofline(args, roof, units_per_launch):
     H = args.pmi_hidden
     flop_pair = 2.0 * (12 * H + 3 * H * H + H)               # 101 632 at H = 128
     hp = (H + 31) // 32 * 32
-    scheme_env = os.environ.get("UAVTRACK_PMI_SCHEME", "")
-    fp32_forced = os.environ.get("UAVTRACK_PMI_FP32", "0") not in ("", "0") or scheme_env == "fp32"
-    split = 64 <= hp <= 128 and not fp32_forced
-    # f16 x 3, pairs on the lanes (pmi_score_t3_kernel) unless forced otherwise; the library itself falls back to bf16 x 6 for networks whose
-    # operands could leave f16's range (none of the synthetic / reference-initialised ones do)
-    scheme = "fp32" if not split else (scheme_env if scheme_env in ("x6", "h3") else "t3")
+    # which kernel scored the pairs: the library says (uavtrack_pmi_info) -- f16 x 3 ("t3") by default, bf16 x 6 ("x6") for
+    # networks beyond f16's range or when pinned, fp32 MFMA for widths the split kernels are not built for
+    lib_scheme = (roof.get("pmi_info") or {}).get("scheme") or "fp32"
+    scheme = {"f16x3": "t3", "bf16x6": "x6", "fp32": "fp32"}[lib_scheme]
+    split = scheme != "fp32"
     call_s = sum(roof["ms"]) * 1e-3
     sc = roof["kernels"].get("scorer", {"ms": 0.0, "launches": 0})
     scorer_s = sc["ms"] * 1e-3 if sc["launches"] else call_s
@@ -443,9 +490,7 @@ def pmi_roofline(args, roof, units_per_launch):
     common = {
         "traffic": traffic, "traffic_source": traffic_src, "flop_per_pair": flop_pair, "pairs_scored": pairs,
         "pairs_per_agent_step": pairs / (units_per_launch * roof["launches"]),
-        "timing": "library-side HIP events on the launch stream around every scorer launch of the fixed leg "
-                  "(uavtrack_set_profiling); whole_call_* divide by the events around the uavtrack_step_many calls instead "
-                  "(rollout + scorer + mix + episode return of every chunk)",
+        "rescored_chunks": (roof.get("pmi_info") or {}).get("rescored_chunks", 0),
         "scorer_ms_per_launch": scorer_s * 1e3 / roof["launches"],
         "fp32_equivalent_tflops": tf_scorer, "fp32_equivalent_over_fp32_mfma_peak": tf_scorer / FP32_MFMA_PEAK_TFLOPS,
         "whole_call_fp32_equivalent_tflops": tf_call,
@@ -463,16 +508,10 @@ def pmi_roofline(args, roof, units_per_launch):
             "bound": "mfma", "kernel": f"pmi_score_{scheme}_kernel<{hp}>", "achieved": executed / scorer_s / 1e12,
             "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": executed / scorer_s / 1e12 / BF16_MFMA_PEAK_TFLOPS,
             "whole_call_frac": executed / call_s / 1e12 / BF16_MFMA_PEAK_TFLOPS, "mfma_products_per_fp32_product": nprod, **common,
-            "peak_note": "f16 / bf16 MFMA dense peak (~2.5 PFLOP/s, MI355X_MICROARCH.md); executed flops = 3 (f16 split) or 6 (bf16 "
-                         "split) MFMAs per fp32 product; fp32_equivalent_* restate the same time as plain fp32 work against the "
-                         "157.3 TFLOP/s fp32-MFMA peak.  The peak is the nominal one (2.4 GHz): under this kernel the device holds "
-                         "~1.88 GHz (SQ_BUSY_CU_CYCLES / duration, profiles/r03pmi_summary.md), where its matrix pipes are busy "
-                         "~71 % of the cycles (SQ_VALU_MFMA_BUSY_CYCLES)",
         }
     return {
         "bound": "mfma", "kernel": f"pmi_score_kernel<{hp}>", "achieved": tf_scorer, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": tf_scorer / FP32_MFMA_PEAK_TFLOPS, "whole_call_frac": tf_call / FP32_MFMA_PEAK_TFLOPS, **common,
-        "peak_note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak = fp32 vector peak, MI355X_MICROARCH.md",
     }
 
 
@@ -492,9 +531,6 @@ def hbm_roofline(args, roof, B, N, M):
         "kernel_avg_ms": kern_ms,
         "frac_at_median_call": bytes_unit * units / (roof["median_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "frac_at_slowest_call": bytes_unit * units / (roof["max_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "timing": f"fixed leg, independent of --steps: {roof['launches']} launches of {roof['T']} steps (reset before each) directly "
-                  f"behind {roof['untimed']} untimed ones, all enqueued before the first event is waited on; HIP events on the "
-                  "launch stream around the kernel (library side) and around every call",
         **leg_summary(roof),
     }
     if src:
@@ -619,7 +655,7 @@ def extras(uavtrack, args, B, device, bytes_unit):
     out["per_step_launch"] = {
         "agent_steps_per_s": B * N * k / r1["wall_s"], "ms_per_step": r1["wall_s"] * 1e3 / k,
         "ms_per_step_all_runs": [r["wall_s"] * 1e3 / k for r in runs],
-        "note": "uavtrack_step eager from Python/ctypes, best of three 400-step runs; host-launch bound",
+        "what": "uavtrack_step, one launch per step, pre-bound, best of three 400-step runs",
     }
     # a batch that fills the chip (SURVEY 8d 'bandwidth-saturating batch'), measured like the roofline leg
     # (200-step launches like the headline leg when the 17 GB of outputs fit comfortably; 50-step launches otherwise --
@@ -679,7 +715,8 @@ def extras(uavtrack, args, B, device, bytes_unit):
     dt = time.perf_counter() - t0
     cl["actor_fused"] = {"agent_steps_per_s": B * N * 1000 / dt, "ms_per_step": dt * 1e3 / 1000}
     env.close()
-    cl["note"] = ("reference-shaped shared actor (FnnPolicyNet 12-128-12 softmax as in configs/MAAC.yaml, random "
+    if VERBOSE:
+      cl["note"] = ("reference-shaped shared actor (FnnPolicyNet 12-128-12 softmax as in configs/MAAC.yaml, random "
                   "init) + categorical sample + uavtrack_step_accumulate, all on device; eager/graph = the actor "
                   "forward and the sample as PyTorch ops, graph = 10 steps per HIP-graph replay; actor_graph = the same "
                   "with the library's own actor kernel (uavtrack_actor_actions); actor_chunks = BatchedRollout(fuse_chunks=True): "
@@ -691,8 +728,40 @@ def extras(uavtrack, args, B, device, bytes_unit):
     return out
 
 
+def configs_summary(line, B, N, M, args):
+    """Every measured configuration in a few numbers each, as the last key of the line (< 2 KB): G agent-steps/s, the
+    roofline fraction of the configuration's dominant kernel and that kernel's ms per 200-step launch."""
+    def r3(x):
+        return None if x is None else float(f"{x:.4g}")
+    rl = line["roofline"]
+    out = [{"cfg": f"{B}x{N}x{M} {args.dim}D {args.reward} (timed region)", "G": r3(line["value"] / 1e9), "ms_per_step": r3(line["ms_per_step"]),
+            "frac": r3(rl["frac"]), "bound": rl["bound"], "kernel_ms": r3(rl.get("kernel_avg_ms", rl.get("scorer_ms_per_launch"))),
+            "roofline_leg_G": r3(B * N * rl["steps_per_launch"] / (rl["avg_launch_ms"] * 1e-3) / 1e9)}]
+    for ent in line.get("other_configs") or []:
+        if not isinstance(ent, dict) or "roofline" not in ent:
+            continue
+        r = ent["roofline"]
+        e = {"cfg": ent["config"], "G": r3(ent["agent_steps_per_s"] / 1e9), "frac": r3(r["frac"]), "bound": r["bound"],
+             "kernel_ms": r3(r.get("kernel_avg_ms", r.get("scorer_ms_per_launch"))), "call_ms": r3(r["avg_launch_ms"])}
+        if "kernel_ms_per_launch" in r:
+            e["kernels_ms"] = {k: r3(v) for k, v in r["kernel_ms_per_launch"].items()}
+        out.append(e)
+    if "saturating_batch" in line:
+        sb = line["saturating_batch"]
+        out.append({"cfg": "65536x20x10 2D raw (chip-filling)", "G": r3(sb["agent_steps_per_s"] / 1e9), "frac": r3(sb["roofline_frac"]),
+                    "bound": "hbm", "kernel_ms": r3(sb["avg_launch_ms"])})
+    if "closed_loop" in line:
+        out.append({"cfg": "closed loop 4096x20x10, G agent-steps/s", **{k: r3(v["agent_steps_per_s"] / 1e9)
+                                                                      for k, v in line["closed_loop"].items() if isinstance(v, dict) and "agent_steps_per_s" in v}})
+    if "per_step_launch" in line:
+        out.append({"cfg": "T=1 launches", "G": r3(line["per_step_launch"]["agent_steps_per_s"] / 1e9), "us_per_step": r3(line["per_step_launch"]["ms_per_step"] * 1e3)})
+    return out
+
+
 def worker(args):
     """One rank.  WORLD_SIZE / RANK / LOCAL_RANK come from the launcher (spawn_ranks or torchrun)."""
+    global VERBOSE
+    VERBOSE = bool(args.verbose)
     args.cooperative = 0.0 if args.reward == "raw" else 0.3       # configs/MAAC.yaml vs MAAC-G/MAAC-R.yaml
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -729,7 +798,11 @@ def worker(args):
     res = time_config(uavtrack, args, B, args.steps, args.warmup, args.rollout, device,
                       dist=dist if world > 1 else None, env_offset=rank * B, total_envs=world * B)
     wall = torch.tensor([res["wall_s"]], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+    rank_walls = [float(wall.item())]
     if world > 1:
+        allw = [torch.zeros_like(wall) for _ in range(world)]
+        dist.all_gather(allw, wall)
+        rank_walls = [float(w.item()) for w in allw]
         dist.all_reduce(wall, op=dist.ReduceOp.MAX)
     wall_s = float(wall.item())
 
@@ -747,6 +820,9 @@ def worker(args):
             "unit": "agent-steps/s",
             "n_gpus": world,
             "rccl_world_size": rccl_world,
+            "backend": ("rccl" if args.backend == "nccl" else args.backend) if world > 1 else None,
+            "ms_per_step_per_rank": {"min": min(rank_walls) * 1e3 / args.steps, "max": max(rank_walls) * 1e3 / args.steps},
+            "gather": res["gather"],
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": wall_s * 1e3 / args.steps,
@@ -816,6 +892,7 @@ def worker(args):
             line["cpu_baseline"] = cb
             if "value" in cb:
                 cb["gpu_over_cpu"] = value / cb["value"]
+        line["configs"] = configs_summary(line, B, N, M, args)       # LAST key: the tail of stdout is what the driver's record keeps
         print(json.dumps(line), flush=True)
 
     if world > 1:

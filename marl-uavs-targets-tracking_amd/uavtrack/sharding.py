@@ -76,3 +76,93 @@ def gather_rollout_summary(ep_sums, n_envs_total: Optional[int] = None, group=No
     global env id.  Uneven shards (n_envs_total % world != 0) are padded for the
     collective and trimmed afterwards."""
     return gather_rollout_summary_async(ep_sums, n_envs_total, group).wait()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The learner's side of a sharded rollout.  The reference has ONE learner that consumes (state, action, reward,
+# next_state) transitions (train.py:176-194, 250-252); with the rollouts on R ranks it needs a sample of every rank's
+# transitions, not the trajectories themselves (1 GB per rank and rollout at 4096 x 20 x 200).  Each rank draws K of its
+# own transitions, packs them into one [K, 28] int32 block (bit views: nothing is converted) and ONE all-gather per rollout
+# hands every rank -- the learner among them -- the R K sampled rows, ready for DeviceReplayBuffer.add().
+
+TRANSITION_WORDS = 12 + 1 + 1 + 12 + 2      # state, action, reward, next_state, global transition id (int64)
+
+
+def sample_local_transitions(obs_in, out, k: int, env_offset: int = 0, n_envs_total: Optional[int] = None, generator=None):
+    """K transitions of this rank's rollout, uniformly without replacement: out = {obs [T,B,N,12], actions [T,B,N],
+    reward [T,B,N]} (a step_many / run_actor result plus the actions that drove it), obs_in [B,N,12] what the policy saw
+    first.  Returns {"states" [K,12], "actions" [K] int32, "rewards" [K], "next_states" [K,12], "index" [K] int64}; index =
+    (t * B_total + env_offset + b) * N + i, the transition's place in the UNSHARDED rollout's [T, B_total, N] grid (for
+    priorities, de-duplication, and the tests).  The [T+1] state array of transitions_from_rollout is never built."""
+    import torch
+    obs, act, rew = out["obs"], out["actions"], out["reward"]
+    T, B, N = rew.shape
+    n = T * B * N
+    if not (0 < k <= n):
+        raise ValueError(f"k = {k} outside (0, {n}] transitions of this rollout")
+    if n_envs_total is None:
+        n_envs_total = B
+    dev = rew.device
+    pick = torch.randperm(n, device=dev, generator=generator)[:k]
+    t, rem = pick // (B * N), pick % (B * N)
+    b, i = rem // N, rem % N
+    prev = obs[(t - 1).clamp(min=0), b, i]
+    states = torch.where((t == 0).unsqueeze(1), obs_in[b, i], prev)
+    return {"states": states, "actions": act[t, b, i].to(torch.int32), "rewards": rew[t, b, i],
+            "next_states": obs[t, b, i], "index": (t * n_envs_total + env_offset + b) * N + i}
+
+
+def _pack_transitions(s):
+    import torch
+    k = s["actions"].shape[0]
+    return torch.cat([s["states"].contiguous().view(torch.int32), s["actions"].view(k, 1),
+                      s["rewards"].contiguous().view(torch.int32).view(k, 1), s["next_states"].contiguous().view(torch.int32),
+                      s["index"].contiguous().view(torch.int32).view(k, 2)], dim=1).contiguous()
+
+
+def _unpack_transitions(blk):
+    import torch
+    return {"states": blk[:, 0:12].contiguous().view(torch.float32), "actions": blk[:, 12].contiguous(),
+            "rewards": blk[:, 13].contiguous().view(torch.float32), "next_states": blk[:, 14:26].contiguous().view(torch.float32),
+            "index": blk[:, 26:28].contiguous().view(torch.int64).view(-1)}
+
+
+class TransitionGather:
+    """Handle of one in-flight transition gather; wait() -> the dict of sample_local_transitions with R K rows, rank-major."""
+
+    def __init__(self, work, out, dev, world=1, passthrough=None):
+        self._work, self._out, self._dev, self._world, self._result = work, out, dev, world, passthrough
+
+    @property
+    def nbytes_per_rank(self) -> int:
+        """bytes each rank contributes to the collective (0 without a process group)"""
+        return 0 if self._out is None else self._out.numel() * 4 // self._world
+
+    def wait(self):
+        if self._result is None:
+            if self._work is not None:
+                self._work.wait()
+            self._result = _unpack_transitions(self._out.to(self._dev))
+        return self._result
+
+
+def gather_transitions_async(sample, group=None) -> TransitionGather:
+    """Start the all-gather of every rank's K sampled transitions (equal K on all ranks) and return at once; like
+    gather_rollout_summary_async it runs from a private packed copy on RCCL's own stream."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return TransitionGather(None, None, None, passthrough=dict(sample))
+    world = dist.get_world_size(group)
+    send = _pack_transitions(sample)
+    dev = send.device
+    if dev.type == "cuda" and dist.get_backend(group) == "gloo":
+        send = send.cpu()          # rehearsal on gloo: stage through the host
+    out = torch.empty((world * send.shape[0], TRANSITION_WORDS), dtype=torch.int32, device=send.device)
+    work = dist.all_gather_into_tensor(out, send, group=group, async_op=True)
+    return TransitionGather(work, out, dev, world)
+
+
+def gather_transitions(sample, group=None):
+    """Blocking form: {"states" [R K, 12], "actions", "rewards", "next_states", "index"} on every rank."""
+    return gather_transitions_async(sample, group).wait()

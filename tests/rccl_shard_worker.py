@@ -53,9 +53,19 @@ def main():
     src.zero_()
     full = gather_rollout_summary(out["ep_sums"], n_envs_total=a.envs)
     assert torch.equal(handle.wait(), full)
+    # the learner-side exchange: K sampled transitions per rank, one all-gather (uavtrack.sharding.gather_transitions)
+    from uavtrack.sharding import gather_transitions, sample_local_transitions
+    obs_in = torch.full((cnt, 20, 12), -1.0, device=device)            # (any fixed first observation will do for the check)
+    roll = dict(obs=out["obs"], actions=act, reward=out["reward"])
+    sample = sample_local_transitions(obs_in, roll, 512, env_offset=off, n_envs_total=a.envs,
+                                      generator=torch.Generator(device=device).manual_seed(50 + rank))
+    tr = gather_transitions(sample)
+    assert tr["states"].shape == (world * 512, 12) and tr["states"].device == device
+    assert torch.equal(tr["next_states"][rank * 512:(rank + 1) * 512], sample["next_states"])
     torch.cuda.synchronize(device)
     if rank == 0:
         np.save(a.out, full.cpu().numpy())
+        np.savez(a.out + ".transitions.npz", **{k: v.cpu().numpy() for k, v in tr.items()})
     dist.barrier()
     dist.destroy_process_group()
     env.close()

@@ -982,20 +982,21 @@ def test_bench_contract_line(uavtrack):
     assert "1 x 20 steps" in cfg["launch"] and "200 steps per call" not in cfg["launch"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
-    assert rf["steps_per_launch"] == 200 and rf["launches_timed"] >= 5 and len(rf["launch_ms"]) == rf["launches_timed"]
+    assert rf["steps_per_launch"] == 200 and rf["launches_timed"] >= 5 and "launch_ms" not in rf     # (per-launch arrays: --verbose only)
     assert rf["agent_steps_per_launch"] == 4096 * 20 * 200
     # achieved = algorithmic bytes / the rollout kernel's own average duration (library-side HIP events around the kernel);
     # the events around the calls agree with it
     want = rf["algorithmic_bytes_per_agent_step"] * rf["agent_steps_per_launch"] / (rf["kernel_avg_ms"] * 1e-3) / 1e9
     assert abs(rf["achieved"] - want) / want < 1e-9 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
-    assert abs(rf["kernel_ms"]["rollout"]["ms_per_launch"] - rf["kernel_avg_ms"]) < 1e-9
+    assert abs(rf["kernel_ms_per_launch"]["rollout"] - rf["kernel_avg_ms"]) < 1e-5
     assert 0.97 * rf["avg_launch_ms"] < rf["kernel_avg_ms"] <= rf["avg_launch_ms"] * 1.01
     assert rf["launches_timed"] >= 10 and rf["launches_untimed_before"] >= 3
     assert rf["min_launch_ms"] <= rf["median_launch_ms"] <= rf["max_launch_ms"]
-    assert 0.41 < rf["frac"] < 1.0                            # round 1: 0.345, round 2: 0.39-0.42, round 3: 0.45-0.49 (box-dependent) on this launch shape
-    assert rf["frac_at_slowest_call"] > 0.38
+    # sanity floors only (a correctness suite must not fail on a busy box; measured 0.45-0.49 box to box, and
+    # tools/perf_floor.py holds the round's real thresholds): a third of the measured figure would be a broken build
+    assert 0.25 < rf["frac"] < 1.0 and rf["frac_at_slowest_call"] > 0.15
     # back-to-back launches at loaded clocks: no host latency inside an event pair, no post-idle ramp (tools/drift.py)
-    assert max(rf["launch_ms"]) < 1.12 * min(rf["launch_ms"])
+    assert rf["max_launch_ms"] < 1.5 * rf["min_launch_ms"]
     # the other single-GPU BASELINE configurations ride on the default line (--no-extras does not drop them)
     oc = {c["config"].split(" ")[0] + (" dense" if "dense" in c["config"] else " H64" if "hidden 64" in c["config"] else ""): c for c in d["other_configs"]}
     assert set(oc) == {"configs[2]", "configs[2] H64", "configs[3]", "configs[2] dense"}
@@ -1006,15 +1007,21 @@ def test_bench_contract_line(uavtrack):
             assert r2["bound"] == "mfma" and r2["unit"] == "TFLOP/s" and r2["peak"] == 2500.0 and "pmi_score_t3_kernel" in r2["kernel"]
             assert 0.1 < r2["pairs_per_agent_step"] < 1.0 and r2["scorer_ms_per_launch"] < r2["avg_launch_ms"]
             assert r2["fp32_equivalent_over_fp32_mfma_peak"] > 1.0          # past what the fp32 matrix pipe could do at all
-            assert c["agent_steps_per_s"] > (11.5e9 if "H64" in key else 4.5e9 if "dense" in key else 8.0e9)     # round 3 final: 13.6-14 / 5.4-5.6 / 9.2-9.6 G
+            assert c["agent_steps_per_s"] > (6e9 if "H64" in key else 2.5e9 if "dense" in key else 4e9)     # sanity floors (round 3: 13.6-14 / 5.4-5.6 / 9.2-9.6 G)
+            assert r2["rescored_chunks"] == 0
             assert (r2["pairs_per_agent_step"] > 0.4) == ("dense" in key)
         else:
             assert r2["bound"] == "hbm" and abs(r2["algorithmic_bytes_per_agent_step"] - 124.1) < 1e-9
-            assert r2["agent_steps_per_launch"] == 8192 * 50 * 200 and r2["frac"] > 0.28
+            assert r2["agent_steps_per_launch"] == 8192 * 50 * 200 and r2["frac"] > 0.15
     if rf["traffic"] is not None:                             # only ever the profile of exactly this launch shape
         assert "T200" in rf["traffic_source"] or "4096x20x10" in rf["traffic_source"] or rf["traffic"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 1e5 and "sample" in cb
+    # the compact list of every measured configuration is the LAST key of the line and fits the tail the driver keeps
+    assert list(d)[-1] == "configs" and len(json.dumps(d["configs"])) < 2000
+    cs = d["configs"]
+    assert len(cs) == 5 and all(0.0 < c["frac"] < 1.0 and c["G"] > 1.0 and c["kernel_ms"] > 0 for c in cs)
+    assert [c["bound"] for c in cs] == ["hbm", "mfma", "mfma", "hbm", "mfma"]
 
 
 def test_example_training_loop_runs(uavtrack):

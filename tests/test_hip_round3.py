@@ -375,6 +375,20 @@ def test_two_rank_shard_and_gather(uavtrack, tmp_path, backend):
     want = env.step_many(act)["ep_sums"].cpu().numpy()
     assert got.shape == (total, 5)
     np.testing.assert_array_equal(got, want)
+    # the transitions rank 0 received from both ranks (gather_transitions): each row is the row of the unsharded rollout
+    # its global index names
+    env.reset(seed=42, episode=0)
+    full = env.step_many(act)
+    tr = np.load(str(tmp_path / f"gather_{backend}.npy") + ".transitions.npz")
+    idx = torch.from_numpy(tr["index"]).cuda()
+    assert idx.shape == (1024,) and idx.unique().numel() == 1024
+    t, rem = idx // (total * 20), idx % (total * 20)
+    b, i = rem // 20, rem % 20
+    np.testing.assert_array_equal(tr["next_states"], full["obs"][t, b, i].cpu().numpy())
+    np.testing.assert_array_equal(tr["rewards"], full["reward"][t, b, i].cpu().numpy())
+    np.testing.assert_array_equal(tr["actions"], act[t, b, i].cpu().numpy())
+    prev = torch.where((t == 0)[:, None], torch.full((1, 12), -1.0, device="cuda"), full["obs"][(t - 1).clamp(min=0), b, i])
+    np.testing.assert_array_equal(tr["states"], prev.cpu().numpy())
     env.close()
 
 

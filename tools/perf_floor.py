@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Performance floors of the round, kept OUT of the correctness suite (a busy or slower box must not fail `pytest -m gpu`):
+
+    python bench.py > gpurun_out/bench.json && python tools/perf_floor.py gpurun_out/bench.json
+
+Reads the bench line's compact `configs` list and checks each configuration against the floor below (about 7 % under what
+the round measured on the pool's boxes).  Exit code 1 and a table when one is missed."""
+import json
+import sys
+
+FLOORS = {   # cfg substring -> (key, floor)
+    "4096x20x10 2D raw (timed region)": ("frac", 0.43),
+    "configs[2] MAAC-R, PMI hidden 128": ("G", 9.0),
+    "configs[2] MAAC-R, PMI hidden 64": ("G", 13.0),
+    "configs[3] 3-D": ("frac", 0.30),
+    "chip-filling": ("frac", 0.55),
+}
+
+
+def main(path):
+    line = json.loads([ln for ln in open(path).read().splitlines() if ln.strip().startswith("{")][-1])
+    bad = 0
+    for c in line["configs"]:
+        for sub, (key, floor) in FLOORS.items():
+            if sub in c["cfg"] and key in c:
+                ok = c[key] >= floor
+                bad += not ok
+                print(f"{'ok  ' if ok else 'MISS'} {c['cfg']:<70s} {key} = {c[key]:<8g} floor {floor}")
+    cl = [c for c in line["configs"] if c["cfg"].startswith("closed loop")]
+    if cl:
+        print("closed loop:", {k: v for k, v in cl[0].items() if k != "cfg"})
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1]))
