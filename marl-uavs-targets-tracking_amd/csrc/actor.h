@@ -4,28 +4,38 @@
 // wavefront, shared by the stand-alone policy kernel and the fused actor rollout so that both produce
 // the same bits.
 //
-// One lane = one UAV, but the two Linear layers are GEMM-shaped (64 samples x 12 x H and 64 x H x 16
-// per wavefront-step) and every lane needs every weight, so they run on the matrix cores, transposed:
-//     Ht [H x 64]  = relu(W1 [H x 12] . Xt [12 x 64] + b1)        3 k-steps of v_mfma_f32_16x16x4_f32
-//     Lt [16 x 64] = W2 [16 x H] . Ht [H x 64] + b2               H/4 k-steps
-// In the transposed form the weights are the A operand (streamed from L1/L2 as ready-made fragments,
-// one coalesced 256-B load per fragment), the samples are the B/N side, and -- the point of the layout --
-// the accumulator fragment of the first GEMM *is* the B fragment of the second: D[i = 4*(l/16) + v][j =
-// l%16] in register v of lane l is B[k = l/16][j = l%16] for the k-step made of hidden units
-// {v, 4 + v, 8 + v, 12 + v} of the 16-unit block, so the hidden layer never leaves its registers (the
-// k-order of a sum is free; W2's fragments are packed in that order).  Only the 12 inputs and the 16
-// logits of a sample cross lanes, through 5 KB of LDS private to the wavefront.
-// fp32 MFMA throughout (fp32 parity with the torch actor, 1e-5 on the probabilities); measured against
-// a first version that fed v_pk_fma_f32 from scalar loads (weights as SGPR operands), which was bound
-// by scalar-cache bandwidth: 15.6 -> see DESIGN.md for the closed-loop numbers.
+// One lane = one UAV, but the two Linear layers are GEMM-shaped (64 samples x 12 x H and 64 x H x na per
+// wavefront-step) and every lane needs every weight, so they run on the matrix cores, transposed (weights are the
+// A operand, the 64 samples the columns):
+//     Ht [H x 64]  = relu(W1 [H x 16] . Xt [16 x 64])       inputs 0..11, input 12 = 1 carries b1, 13..15 = 0
+//     Lt [32 x 64] = W2 [32 x H] . Ht [H x 64]              rows >= na are zero
+// on the 16-BIT matrix cores at fp32 accuracy (round 4; rounds 1-3 ran 224 fp32-input MFMAs per wavefront-step, 1/16 of the
+// 16-bit rate): an fp32 value is the two-term f16 sum v = hi + lo, hi = f16(v) toward zero, lo = f16(v - hi) -- 22
+// significant bits, the remainder representable down to 2^-24 of a block scale the host folds into each layer (powers of
+// two: exact) -- and a product is THREE v_mfma_f32_32x32x16_f16 with exact products and fp32 accumulation,
+//     w v = wl vh + wh vl + wh vh      (small terms first; wl vl < 2^-22 |w v| is dropped),
+// 72 of them per wavefront-step at H = 128 (24 for layer 1, 48 for layer 2) against 224 of twice the cycles before.
+// The scorer of the MAAC-R reward (pmi_kernel.hip) carries the error analysis and the numpy emulation of this split.
 //
-// Device weight blob (uavtrack_set_actor_weights packs it), in units of one fragment = 64 floats, lane
-// l at offset l; MT action tiles of 16 rows (1 in 2-D, 3 for the 3-D action space); HB = ceil(H/16) blocks
-// of 7 + 4*MT fragments, then 4*MT fragments of b2:
-//   block a:  W1 s=0..2        : W1[16a + l%16][4s + l/16]
-//             b1 v=0..3        : b1[16a + 4*(l/16) + v]
-//             W2 tile t, v=0..3: W2[16t + l%16][16a + 4*(l/16) + v]   (rows >= na*nc and units >= H are zero)
-//   tail:     b2 tile t, v=0..3: b2[16t + 4*(l/16) + v]
+// No value crosses lanes through memory:
+//   * a 32x32x16 B operand holds, in lane l, eight consecutive k of column l % 32 (k = 0..7 in lanes 0..31, 8..15 in
+//     lanes 32..63), and the two column tiles of a wavefront are samples 0..31 and 32..63: lane l owns sample l, so tile 0
+//     needs inputs 8..15 of sample l in lane l + 32 and tile 1 inputs 0..7 of sample l + 32 in lane l -- ONE
+//     v_permlane32_swap_b32 per register pair builds both tiles' operand registers;
+//   * the accumulator of layer 1 (lane l: column l % 32, rows (r & 3) + 8 (r >> 2) + 4 (l >> 5)) IS layer 2's B operand
+//     once converted: registers r = 8 h .. 8 h + 7 of the two half-wavefronts are the 16 k of k-step (tile, h) -- the
+//     k-order of a sum is free, W2's fragments are packed in that order -- so the hidden layer never leaves its lane;
+//   * layer 2's accumulator spreads a sample's logits over lanes l and l + 32 of either column tile; the same swap
+//     instruction (tile 0's register r against tile 1's) hands every lane the logits of its own sample.
+// ReLU is the v_med3_f32 that also caps a value at the f16 range (an observation next to the origin can be arbitrarily
+// large, uav.py:165; saturation instead of inf/NaN), so remainders are non-negative and need no clamp of their own.
+//
+// Device weight blob (uavtrack_set_actor_weights packs it): 128 header floats { [0] 1 / (T1 T2), [16 .. 16 + 32 AT) b2 },
+// then per tile a of 32 hidden units 2 + 4 AT fragments of 64 lanes x 8 f16 (16 B per lane, lane-major):
+//   W1 hi, W1 lo        lane l, element j: T1 * W1[32 a + l % 32][k = 8 (l >> 5) + j]   (k = 12: b1, k > 12: 0)
+//   per action tile t (AT = 1: the reference's 12 actions; AT = 2: the 3-D action space, up to 48) and half h = 0, 1:
+//   W2 hi, W2 lo        lane l, element j: T2 * W2[32 t + l % 32][unit 32 a + (r & 3) + 8 (r >> 2) + 4 (j >> 3 ... see pack)]
+// T1, T2 powers of two: T1 x (bound of |pre-activation| over nominal observation ranges) <= 512 and T x max |w| <= 16384.
 //
 // Sampling: torch's Categorical draws from torch's own generator, which has no place inside a kernel;
 // here the draw is the inverse CDF of the same probabilities at a Philox uniform keyed by
@@ -34,147 +44,235 @@
 #include "internal.h"
 #include "philox.h"
 
+#include <cmath>
+#include <cstring>
+
 namespace uavtrack {
 
 constexpr int kActorObs = UAVTRACK_OBS_DIM;            // 12
-constexpr int kActorLdsFloats = 64 * 20;               // per wavefront: logits at a 20-float stride (conflict-free b128)
-// Action tiles of 16 rows in the second GEMM: MT = 1 serves the reference's action space (na = 12), MT = 3 the
-// 3-D action space of our own spec (na * nc = 36, up to 48).  Per-lane softmax slots: 12 / 48.
-constexpr int actor_tiles(bool z3) { return z3 ? 3 : 1; }
-constexpr int actor_slots(int mt) { return mt == 1 ? 12 : 16 * mt; }
-constexpr int actor_frags_per_block(int mt) { return 7 + 4 * mt; }   // W1 x3, b1 x4, W2 x4 per tile
+constexpr int kActorHeaderFloats = 128;
+constexpr int kActorB2Offset = 16;
+// 32-row action tiles of the second GEMM: 1 serves the reference's action space (na = 12), 2 the 3-D action space of our
+// own spec (na * nc = 36, up to 48).  Per-lane softmax slots: 12 / 48.
+constexpr int actor_tiles(bool z3) { return z3 ? 2 : 1; }
+constexpr int actor_slots(int at) { return at == 1 ? 12 : 48; }
+constexpr int actor_frags_per_tile(int at) { return 2 + 4 * at; }      // W1 hi, lo; per action tile W2 (half 0, 1) x (hi, lo)
 
-typedef float actor_v4 __attribute__((ext_vector_type(4)));
-
-inline int actor_blocks(int hidden) { return (hidden + 15) / 16; }
-inline size_t actor_blob_floats(int hidden, int mt)
+inline int actor_blocks(int hidden) { return (hidden + 31) / 32; }     // 32-unit tiles of the hidden layer
+inline size_t actor_blob_floats(int hidden, int at)
 {
-    return ((size_t)actor_blocks(hidden) * actor_frags_per_block(mt) + 4 * mt) * 64;
+    return kActorHeaderFloats + (size_t)actor_blocks(hidden) * actor_frags_per_tile(at) * 64 * 4;
 }
 
-// Host side: torch layouts (w1 [H][12], b1 [H], w2 [A][H], b2 [A]) -> fragment order above (tile t of W2 / b2
-// holds actions 16t .. 16t+15; its fragments follow tile t-1's).
-inline void pack_actor_blob(const float *w1, const float *b1, const float *w2, const float *b2, int H, int A, int mt, float *blob)
+// hidden unit held by accumulator register r of a lane in half-wavefront kh (32x32 MFMA C/D layout)
+inline int actor_unit_of(int r, int kh) { return (r & 3) + 8 * (r >> 2) + 4 * kh; }
+
+// Host side: torch layouts (w1 [H][12], b1 [H], w2 [A][H], b2 [A]) -> the blob above.  xb[12]: nominal bounds of |obs_k|
+// (they size T1; a value beyond them saturates at 60000 / T1 inside the kernel instead of overflowing).
+inline void pack_actor_blob(const float *w1, const float *b1, const float *w2, const float *b2, int H, int A, int at,
+                            const double *xb, float *blob)
 {
-    const int HB = actor_blocks(H), FB = actor_frags_per_block(mt);
-    for (int a = 0; a < HB; ++a) {
-        float *blk = blob + (size_t)a * FB * 64;
-        for (int l = 0; l < 64; ++l) {
-            const int j = l & 15, g = l >> 4;
-            for (int s = 0; s < 3; ++s) {
-                const int u = 16 * a + j;
-                blk[s * 64 + l] = u < H ? w1[(size_t)u * kActorObs + 4 * s + g] : 0.0f;
-            }
-            for (int v = 0; v < 4; ++v) {
-                const int u = 16 * a + 4 * g + v;
-                blk[(3 + v) * 64 + l] = u < H ? b1[u] : 0.0f;
-                for (int t = 0; t < mt; ++t) {
-                    const int act = 16 * t + j;
-                    blk[(7 + 4 * t + v) * 64 + l] = (u < H && act < A) ? w2[(size_t)act * H + u] : 0.0f;
-                }
+    const int HT = actor_blocks(H), FT = actor_frags_per_tile(at);
+    double act = 0.0, w1max = 0.0, w2max = 0.0;
+    for (int u = 0; u < H; ++u) {
+        double a = std::fabs((double)b1[u]);
+        w1max = std::fmax(w1max, a);
+        for (int k = 0; k < kActorObs; ++k) {
+            a += std::fabs((double)w1[(size_t)u * kActorObs + k]) * xb[k];
+            w1max = std::fmax(w1max, std::fabs((double)w1[(size_t)u * kActorObs + k]));
+        }
+        act = std::fmax(act, a);
+    }
+    for (size_t k = 0; k < (size_t)A * H; ++k) w2max = std::fmax(w2max, std::fabs((double)w2[k]));
+    auto pow2_below = [](double bound, double target) {         // largest 2^e with 2^e * bound <= target, e in [-24, 24]
+        int e = 24;
+        if (bound > 0.0 && std::isfinite(bound)) e = (int)std::floor(std::log2(target / bound));
+        return std::ldexp(1.0, e < -24 ? -24 : (e > 24 ? 24 : e));
+    };
+    const double T1 = std::fmin(pow2_below(act, 512.0), pow2_below(w1max, 16384.0));
+    const double T2 = pow2_below(w2max, 16384.0);
+    memset(blob, 0, actor_blob_floats(H, at) * sizeof(float));
+    blob[0] = (float)(1.0 / (T1 * T2));
+    for (int q = 0; q < A; ++q) blob[kActorB2Offset + q] = b2[q];
+    uint16_t *frag = reinterpret_cast<uint16_t *>(blob + kActorHeaderFloats);
+    auto put = [&](int a, int f, int lane, int j, double v) {                  // hi into fragment f, lo into f + 1
+        const float s = (float)v;
+        const _Float16 hi = (_Float16)s;
+        const _Float16 lo = (_Float16)(s - (float)hi);
+        uint16_t bh, bl;
+        memcpy(&bh, &hi, 2);
+        memcpy(&bl, &lo, 2);
+        frag[(((size_t)a * FT + f) * 64 + lane) * 8 + j] = bh;
+        frag[(((size_t)a * FT + f + 1) * 64 + lane) * 8 + j] = bl;
+    };
+    for (int a = 0; a < HT; ++a)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int row = lane & 31, kh = lane >> 5;
+            for (int j = 0; j < 8; ++j) {
+                // layer 1: row = hidden unit 32 a + row, k = 8 kh + j: inputs 0..11, then the bias on the constant input
+                const int u = 32 * a + row, k = 8 * kh + j;
+                double v = 0.0;
+                if (u < H) v = k < kActorObs ? (double)w1[(size_t)u * kActorObs + k] : (k == kActorObs ? (double)b1[u] : 0.0);
+                put(a, 0, lane, j, T1 * v);
+                // layer 2, k-step (a, half): row = action 32 t + row, k = 8 kh + j <-> the unit the B operand's lane holds there
+                for (int t = 0; t < at; ++t)
+                    for (int half = 0; half < 2; ++half) {
+                        const int unit = 32 * a + actor_unit_of(8 * half + j, kh), q = 32 * t + row;
+                        const double w = (unit < H && q < A) ? (double)w2[(size_t)q * H + unit] : 0.0;
+                        put(a, 2 + 4 * t + 2 * half, lane, j, T2 * w);
+                    }
             }
         }
-    }
-    float *tail = blob + (size_t)HB * FB * 64;
-    for (int l = 0; l < 64; ++l)
-        for (int t = 0; t < mt; ++t)
-            for (int v = 0; v < 4; ++v) {
-                const int act = 16 * t + 4 * (l >> 4) + v;
-                tail[(4 * t + v) * 64 + l] = act < A ? b2[act] : 0.0f;
-            }
 }
 
-// EVERY lane of the wavefront must reach this call together (MFMA ignores EXEC); lanes without a UAV pass
-// zeros and ignore the result.  lds: kActorLdsFloats floats private to this wavefront.
-// mode: UAVTRACK_ACTOR_SAMPLE (inverse-CDF draw) or UAVTRACK_ACTOR_ARGMAX (lowest index on ties).
 struct ActorRng {          // Philox block cache of one UAV (see the draw below)
     Philox4 r;
     uint32_t block;
     bool valid;
 };
 
-template <bool WANT_PROBS, int MT>
-__device__ __forceinline__ int actor_pick(const float (&o)[kActorObs], float *lds, const float *__restrict__ weights,
-                                          int HB, int A, uint64_t genv, uint32_t step, int i, uint32_t k0, uint32_t k1,
+typedef _Float16 actor_h8 __attribute__((ext_vector_type(8)));
+typedef float actor_f16v __attribute__((ext_vector_type(16)));
+typedef unsigned actor_u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ actor_h8 actor_as_h8(actor_u4 v) { return __builtin_bit_cast(actor_h8, v); }
+// two floats -> one word of two f16 (first in the low half), toward zero: saturates at 65504, never inf
+__device__ __forceinline__ unsigned actor_pk(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b)); }
+// f16 pair of the remainders (a - hi.lo, b - hi.hi): one mixed-precision FMA per value (f16 operand * -1 + fp32 operand,
+// rounded once to f16); the remainder of a toward-zero conversion is below one f16 ulp of the value: no overflow
+__device__ __forceinline__ unsigned actor_rem(unsigned hi, float a, float b)
+{
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(hi), "v"(b));
+    return r;
+}
+// lanes 32..63 of `lo_keeps` trade places with lanes 0..31 of `hi_keeps` (v_permlane32_swap_b32): afterwards
+//   lo_keeps: lanes 0..31 unchanged, lane l >= 32 holds what hi_keeps held in lane l - 32
+//   hi_keeps: lanes 32..63 unchanged, lane l < 32 holds what lo_keeps held in lane l + 32
+__device__ __forceinline__ void actor_swap32(unsigned &lo_keeps, unsigned &hi_keeps)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(lo_keeps, hi_keeps, false, false);
+    lo_keeps = r[0];
+    hi_keeps = r[1];
+}
+__device__ __forceinline__ void actor_swap32(float &lo_keeps, float &hi_keeps)
+{
+    unsigned a = __float_as_uint(lo_keeps), b = __float_as_uint(hi_keeps);
+    actor_swap32(a, b);
+    lo_keeps = __uint_as_float(a);
+    hi_keeps = __uint_as_float(b);
+}
+
+constexpr float kActorCap = 60000.0f;       // inside f16's 65504 with room for the toward-zero conversion
+
+// EVERY lane of the wavefront must reach this call together (MFMA and the lane swaps ignore EXEC); lanes without a UAV
+// pass zeros and ignore the result.  weights: the blob; HT = actor_blocks(hidden).
+// mode: UAVTRACK_ACTOR_SAMPLE (inverse-CDF draw) or UAVTRACK_ACTOR_ARGMAX (lowest index on ties).
+template <bool WANT_PROBS, int AT>
+__device__ __forceinline__ int actor_pick(const float (&o)[kActorObs], const float *__restrict__ weights,
+                                          int HT, int A, uint64_t genv, uint32_t step, int i, uint32_t k0, uint32_t k1,
                                           int mode, float *probs, ActorRng &rng)
 {
-    constexpr int FB = actor_frags_per_block(MT), SLOTS = actor_slots(MT);
-    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
-    // ---- the 12 inputs of the 64 samples, regrouped into B fragments: lane l <- obs[16n + l%16][4s + l/16]
+    constexpr int FT = actor_frags_per_tile(AT), SLOTS = actor_slots(AT);
+    const int lane = threadIdx.x & 63;
+    // a tile's fragments: one coalesced 1-KiB load each, L2-resident; the first tile's are requested here, ahead of the
+    // input conversion, every later tile's while its predecessor is being multiplied
+    const actor_u4 *wl = reinterpret_cast<const actor_u4 *>(weights + kActorHeaderFloats) + lane;
+    actor_u4 wf[FT];
+#pragma unroll
+    for (int f = 0; f < FT; ++f) wf[f] = wl[(size_t)f * 64];
+    // ---- the 12 inputs as f16 planes, then as the B operands of the two column tiles (samples 0..31 / 32..63)
+    unsigned xh[2][4], xl[2][4];
     {
-        float4 *xs = reinterpret_cast<float4 *>(lds + lane * kActorObs);
-        xs[0] = make_float4(o[0], o[1], o[2], o[3]);
-        xs[1] = make_float4(o[4], o[5], o[6], o[7]);
-        xs[2] = make_float4(o[8], o[9], o[10], o[11]);
+        unsigned ph[6], pl[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float a = __builtin_amdgcn_fmed3f(o[2 * j], -kActorCap, kActorCap), b = __builtin_amdgcn_fmed3f(o[2 * j + 1], -kActorCap, kActorCap);
+            ph[j] = actor_pk(a, b);
+            pl[j] = actor_rem(ph[j], a, b);
+        }
+        // registers 0..3 of a tile's operand: k = 0..7 (inputs 0..7) in lanes 0..31, k = 8..15 (inputs 8..11, the constant 1
+        // that carries b1, zeros) in lanes 32..63
+        unsigned one = 0x00003C00u, zero = 0u, zl0 = 0u, zl1 = 0u;       // (f16 1.0 in the low half; the lo plane's constant is 0)
+        xh[0][0] = ph[0]; xh[1][0] = ph[4]; actor_swap32(xh[0][0], xh[1][0]);
+        xh[0][1] = ph[1]; xh[1][1] = ph[5]; actor_swap32(xh[0][1], xh[1][1]);
+        xh[0][2] = ph[2]; xh[1][2] = one;   actor_swap32(xh[0][2], xh[1][2]);
+        xh[0][3] = ph[3]; xh[1][3] = zero;  actor_swap32(xh[0][3], xh[1][3]);
+        xl[0][0] = pl[0]; xl[1][0] = pl[4]; actor_swap32(xl[0][0], xl[1][0]);
+        xl[0][1] = pl[1]; xl[1][1] = pl[5]; actor_swap32(xl[0][1], xl[1][1]);
+        xl[0][2] = pl[2]; xl[1][2] = zl0;   actor_swap32(xl[0][2], xl[1][2]);
+        xl[0][3] = pl[3]; xl[1][3] = zl1;   actor_swap32(xl[0][3], xl[1][3]);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    float xf[4][3];
+    actor_h8 bxh[2], bxl[2];
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int s = 0; s < 3; ++s) xf[n][s] = lds[(16 * n + j) * kActorObs + 4 * s + g];
+    for (int t = 0; t < 2; ++t) {
+        bxh[t] = actor_as_h8((actor_u4){xh[t][0], xh[t][1], xh[t][2], xh[t][3]});
+        bxl[t] = actor_as_h8((actor_u4){xl[t][0], xl[t][1], xl[t][2], xl[t][3]});
+    }
 
-    const float *wl = weights + lane;
-    actor_v4 d2[MT][4];
-    {
-        const float *t = wl + (size_t)HB * FB * 64;
+    actor_f16v zero16;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const actor_v4 b2f = {t[(4 * mt) * 64], t[(4 * mt + 1) * 64], t[(4 * mt + 2) * 64], t[(4 * mt + 3) * 64]};
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
+    actor_f16v d2[AT][2];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) d2[mt][n] = b2f;
+    for (int t = 0; t < AT; ++t) { d2[t][0] = zero16; d2[t][1] = zero16; }
+#pragma unroll 1
+    for (int a = 0; a < HT; ++a) {
+        actor_u4 nx[FT];
+        const int an = a + 1 < HT ? a + 1 : a;          // (the last iteration re-requests its own tile: no branch around loads)
+#pragma unroll
+        for (int f = 0; f < FT; ++f) nx[f] = wl[((size_t)an * FT + f) * 64];
+        const actor_h8 w1h = actor_as_h8(wf[0]), w1l = actor_as_h8(wf[1]);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {         // column tile
+            // T1 (W1 x + b1), three products in one accumulator, small terms first
+            actor_f16v d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1l, bxh[c], zero16, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, bxl[c], d1, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, bxh[c], d1, 0, 0, 0);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                // ReLU (and the cap) as one v_med3_f32 per value, hi = f16 toward zero, lo = f16(v - hi) >= 0
+                unsigned hh[4], hl[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v0 = __builtin_amdgcn_fmed3f(d1[8 * half + 2 * j], 0.0f, kActorCap);
+                    const float v1 = __builtin_amdgcn_fmed3f(d1[8 * half + 2 * j + 1], 0.0f, kActorCap);
+                    hh[j] = actor_pk(v0, v1);
+                    hl[j] = actor_rem(hh[j], v0, v1);
+                }
+                const actor_h8 bh = actor_as_h8((actor_u4){hh[0], hh[1], hh[2], hh[3]}), bl = actor_as_h8((actor_u4){hl[0], hl[1], hl[2], hl[3]});
+#pragma unroll
+                for (int t = 0; t < AT; ++t) {
+                    const actor_h8 w2h = actor_as_h8(wf[2 + 4 * t + 2 * half]), w2l = actor_as_h8(wf[3 + 4 * t + 2 * half]);
+                    d2[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2l, bh, d2[t][c], 0, 0, 0);
+                    d2[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h, bl, d2[t][c], 0, 0, 0);
+                    d2[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h, bh, d2[t][c], 0, 0, 0);
+                }
+            }
         }
+#pragma unroll
+        for (int f = 0; f < FT; ++f) wf[f] = nx[f];
     }
-#pragma unroll 2
-    for (int a = 0; a < HB; ++a) {
-        const float *wa = wl + (size_t)a * FB * 64;
-        float wf[FB];
-#pragma unroll
-        for (int f = 0; f < FB; ++f) wf[f] = wa[f * 64];
-        const actor_v4 b1f = {wf[3], wf[4], wf[5], wf[6]};
-        actor_v4 d1[4];
-#pragma unroll
-        for (int n = 0; n < 4; ++n) d1[n] = b1f;
-#pragma unroll
-        for (int s = 0; s < 3; ++s)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) d1[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xf[n][s], d1[n], 0, 0, 0);
-        // ReLU as one v_med3_f32 per element (fmaxf on an MFMA result costs a canonicalising v_max first)
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) d1[n][v] = __builtin_amdgcn_fmed3f(d1[n][v], 0.0f, 3.0e38f);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    d2[mt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[7 + 4 * mt + v], d1[n][v], d2[mt][n], 0, 0, 0);
-    }
-    // ---- logits back to their own lane, one action tile at a time through the same 5 KB: lane l holds actions
-    //      16t + 4*(l/16) .. +3 of samples 16n + l%16
+    // ---- logits to their own lane: register r of tile 0 against register r of tile 1; afterwards every lane holds, of ITS
+    //      sample, action 32 t + (r & 3) + 8 (r >> 2) in the first and that action + 4 in the second
     float lg[SLOTS];
+    {
+        const float inv_scale = weights[0];
+        const float *b2 = weights + kActorB2Offset;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        __builtin_amdgcn_wave_barrier();
+        for (int t = 0; t < AT; ++t)
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
-            *reinterpret_cast<float4 *>(lds + (16 * n + j) * 20 + 4 * g) =
-                make_float4(d2[mt][n][0], d2[mt][n][1], d2[mt][n][2], d2[mt][n][3]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        constexpr int Q = (MT == 1) ? 3 : 4;               // float4 per tile this lane needs (12 of 16 at MT = 1)
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const float4 v = *reinterpret_cast<const float4 *>(lds + lane * 20 + 4 * q);
-            lg[16 * mt * (MT > 1) + 4 * q] = v.x; lg[16 * mt * (MT > 1) + 4 * q + 1] = v.y;
-            lg[16 * mt * (MT > 1) + 4 * q + 2] = v.z; lg[16 * mt * (MT > 1) + 4 * q + 3] = v.w;
-        }
+            for (int r = 0; r < 16; ++r) {
+                const int q0 = 32 * t + (r & 3) + 8 * (r >> 2), q1 = q0 + 4;
+                if (q0 >= SLOTS) continue;
+                float u = d2[t][0][r], v = d2[t][1][r];
+                actor_swap32(u, v);
+                lg[q0] = fmaf(u, inv_scale, b2[q0]);
+                if (q1 < SLOTS) lg[q1] = fmaf(v, inv_scale, b2[q1]);
+            }
     }
-    __builtin_amdgcn_wave_barrier();                 // the next call's input staging must not overtake these reads
-    if (A < SLOTS) {                                 // uniform; the reference's na = 12 fills every slot of MT = 1
+    if (A < SLOTS) {                                 // uniform; the reference's na = 12 fills every slot of AT = 1
 #pragma unroll
         for (int q = 0; q < SLOTS; ++q) lg[q] = (q < A) ? lg[q] : -INFINITY;
     }
@@ -182,9 +280,10 @@ __device__ __forceinline__ int actor_pick(const float (&o)[kActorObs], float *ld
 #pragma unroll
     for (int q = 1; q < SLOTS; ++q) m = fmaxf(m, lg[q]);
     float ex[SLOTS], S = 0.0f;
+    const float mneg = -m * 1.44269504088896340736f;
 #pragma unroll
     for (int q = 0; q < SLOTS; ++q) {
-        ex[q] = __builtin_amdgcn_exp2f((lg[q] - m) * 1.44269504088896340736f);   // masked slots: exp2(-inf) = 0
+        ex[q] = __builtin_amdgcn_exp2f(fmaf(lg[q], 1.44269504088896340736f, mneg));   // masked slots: exp2(-inf) = 0
         S += ex[q];
     }
     if (WANT_PROBS && probs) {

@@ -802,7 +802,13 @@ int uavtrack_set_actor_weights(uavtrack_env *env, const float *w1, const float *
     if (hidden < 1 || hidden > 4096) return fail("uavtrack_set_actor_weights: hidden %d out of range [1, 4096]", hidden);
     const size_t n = actor_blob_floats(hidden, mt);
     std::vector<float> blob(n, 0.0f);
-    pack_actor_blob(w1, b1, w2, b2, hidden, A, mt, blob.data());
+    // nominal bounds of the observation entries (uav.py:156-197: normalised offsets and action differences within [-1, 1],
+    // heading terms within +-2 / +-(1 + v_t / v_u), positions / dc taken up to four field lengths): they size the block
+    // scale of the hidden layer, which keeps a factor 128 of headroom above them and saturates beyond that
+    const uavtrack_config &c = env->cfg;
+    const double vr = 1.0 + c.t_v_max / c.u_v_max, pos = 4.0 * std::fmax(c.x_max, c.y_max) / c.dc;
+    const double xb[12] = {1, 1, 2, 2, 1, 1, 1, vr, vr, pos, pos, 1};
+    pack_actor_blob(w1, b1, w2, b2, hidden, A, mt, xb, blob.data());
     if (env->actor_hidden != hidden) {
         if (env->actor_w) (void)hipFree(env->actor_w);
         env->actor_w = nullptr; env->actor_hidden = 0;
@@ -841,10 +847,6 @@ int uavtrack_run_actor(uavtrack_env *env, int32_t T, uint64_t seed, int32_t mode
     if (obs_in == obs && T > 1)
         return fail("uavtrack_run_actor: obs_in must not alias obs when T > 1 (pass the previous launch's last rows, "
                     "or a copy)");
-    if (rollout_lds_bytes(env->geo, kPolicyActor) > 64 * 1024 || rollout_lds_bytes(env->geo_short, kPolicyActor) > 64 * 1024)
-        return fail("uavtrack_run_actor: the step tables (%zu B) plus the actor's %zu B of LDS per workgroup exceed 64 KiB for "
-                    "n_uav=%d, m_targets=%d; use uavtrack_actor_actions + uavtrack_step for this shape",
-                    env->geo.lds_bytes, rollout_lds_bytes(env->geo, kPolicyActor) - env->geo.lds_bytes, env->cfg.n_uav, env->cfg.m_targets);
     PolicyArgs pol;
     pol.policy = kPolicyActor; pol.obs_in = obs_in; pol.actions_out = actions_out; pol.seed = seed; pol.mode = mode;
     return run_steps(env, T, nullptr, obs, reward, terms, covered, done, ep_sums, stream, "uavtrack_run_actor", false, pol);

@@ -83,8 +83,7 @@ struct StepParams {
     // fused actor rollout (uavtrack_run_actor): actions come from the in-kernel policy network (actor.h)
     const float *obs_in;     // [B][N][12] observation seen at the first step
     const float *actor_w;    // packed weight blob
-    int32_t actor_hblocks, actor_mode;   // 16-unit blocks of the hidden layer
-    int32_t actor_lds_off;               // byte offset of the actor's per-wavefront LDS behind the step tables
+    int32_t actor_hblocks, actor_mode;   // 32-unit tiles of the hidden layer
     // constants
     float x_max, y_max, z_max;
     float dtv_u, dtv_t;          // dt * v_max of UAVs / targets

@@ -83,7 +83,6 @@ struct ActorParams {
 template <int MT>
 __global__ void __launch_bounds__(256) actor_policy_kernel(const ActorParams p)
 {
-    __shared__ float lds[4][kActorLdsFloats];
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = g < (size_t)p.B * p.N;
     float o[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -99,7 +98,7 @@ __global__ void __launch_bounds__(256) actor_policy_kernel(const ActorParams p)
     float *pr = (valid && p.probs) ? p.probs + g * p.A : nullptr;
     ActorRng rng;
     rng.valid = false; rng.block = 0;
-    const int act = actor_pick<true, MT>(o, lds[threadIdx.x >> 6], p.weights, p.hblocks, p.A, (uint64_t)(p.env_offset + b),
+    const int act = actor_pick<true, MT>(o, p.weights, p.hblocks, p.A, (uint64_t)(p.env_offset + b),
                                      (uint32_t)step, i, p.k0, p.k1, p.mode, pr, rng);
     if (valid) p.actions[g] = act;
 }
@@ -120,7 +119,7 @@ hipError_t launch_actor(const uavtrack_env *env, const float *obs, uint64_t seed
     if (actor_tiles(c.dim == 3) == 1)
         hipLaunchKernelGGL(actor_policy_kernel<1>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, p);
     else
-        hipLaunchKernelGGL(actor_policy_kernel<3>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(actor_policy_kernel<2>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

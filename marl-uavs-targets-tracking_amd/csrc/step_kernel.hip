@@ -733,8 +733,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         // ---- P0 (fused actor rollout only): take_action (actor_critic.py:138-148) on the UAV's own previous
         //      observation, still in registers -- no table, no barrier
         if (ACTOR) {     // whole wavefronts: the two layers run on the matrix cores (actor.h)
-            float *alds = reinterpret_cast<float *>(reinterpret_cast<char *>(smem4) + p.actor_lds_off) + (tid >> 6) * kActorLdsFloats;
-            act = actor_pick<false, actor_tiles(Z3)>(o, alds, p.actor_w, p.actor_hblocks, p.na_total, (uint64_t)(p.env_offset + b),
+            act = actor_pick<false, actor_tiles(Z3)>(o, p.actor_w, p.actor_hblocks, p.na_total, (uint64_t)(p.env_offset + b),
                                     (uint32_t)count, i, p.greedy_k0, p.greedy_k1, p.actor_mode, nullptr, arng);
             if (active && p.actions_out) *at(p.actions_out + row, g32 * 4u) = act;
         }
@@ -1366,10 +1365,9 @@ Geometry plan_geometry(const uavtrack_config &cfg, int n_simd, bool allow_small_
     static const int kSmall[] = {64, 128, 256, 512};
     // whole environments per workgroup: as many as there are lanes for, fewer when their tables would not fit
     // the 64 KB of LDS a workgroup may have (few UAVs, many targets: N = 1, M = 70 fits 58 environments, not 64).
-    // The fused actor rollout adds 5 KB per wavefront behind the tables (actor.h): reserved here, so that every
-    // geometry this function returns can also run uavtrack_run_actor.
     auto lds_need = [&](int wgs, int E) {
-        return lds_bytes_for(E, N, cfg.m_targets, cfg.dim == 3, cfg.reward_mode) + (size_t)(wgs / 64) * kActorLdsFloats * sizeof(float);
+        (void)wgs;
+        return lds_bytes_for(E, N, cfg.m_targets, cfg.dim == 3, cfg.reward_mode);
     };
     auto envs_of = [&](int wgs) {
         int E = wgs / N;
@@ -1425,9 +1423,8 @@ Geometry plan_geometry(const uavtrack_config &cfg, int n_simd, bool allow_small_
 
 size_t rollout_lds_bytes(const Geometry &g, int policy)
 {
-    size_t lds = g.lds_bytes;
-    if (policy == kPolicyActor) lds += (size_t)(g.wgs / 64) * kActorLdsFloats * sizeof(float);
-    return lds;
+    (void)policy;               // (the in-kernel actor needs no LDS since round 4: its operands move by lane swaps)
+    return g.lds_bytes;
 }
 
 hipError_t launch_rollout(uavtrack_env *env, const StepParams &p, hipStream_t stream, int policy, const Geometry *geo)
@@ -1448,7 +1445,6 @@ hipError_t launch_rollout(uavtrack_env *env, const StepParams &p, hipStream_t st
     KernelFn fn = pick_kernel(p.N, p.M, env->cfg.reward_mode, env->cfg.dim == 3, &spec, policy, allout, extras, g.lone != 0);
     StepParams q = p;
     q.E = g.envs_per_wg;
-    if (policy == kPolicyActor) q.actor_lds_off = (int32_t)g.lds_bytes;
     hipLaunchKernelGGL(fn, dim3(g.groups), dim3(g.wgs), rollout_lds_bytes(g, policy), stream, q);
     return hipGetLastError();
 }
