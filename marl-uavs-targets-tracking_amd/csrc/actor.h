@@ -46,6 +46,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <utility>
 
 namespace uavtrack {
 
@@ -164,6 +165,12 @@ __device__ __forceinline__ void actor_swap32(float &lo_keeps, float &hi_keeps)
     hi_keeps = __uint_as_float(b);
 }
 
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(<N - 1>)
+template <int... I, class F>
+__device__ __forceinline__ void actor_static_for_impl(std::integer_sequence<int, I...>, F &&f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void actor_static_for(F &&f) { actor_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
 constexpr float kActorCap = 60000.0f;       // inside f16's 65504 with room for the toward-zero conversion
 
 // EVERY lane of the wavefront must reach this call together (MFMA and the lane swaps ignore EXEC); lanes without a UAV
@@ -217,40 +224,85 @@ __device__ __forceinline__ int actor_pick(const float (&o)[kActorObs], const flo
     actor_f16v d2[AT][2];
 #pragma unroll
     for (int t = 0; t < AT; ++t) { d2[t][0] = zero16; d2[t][1] = zero16; }
+    // The two layers as a software pipeline over the units (hidden tile a, column tile c): a wavefront issues in order, an
+    // MFMA occupies the matrix pipe for 32 cycles but the issue port for 8, and the conversion of a finished layer-1 tile
+    // into layer-2 operands is ~20 VALU instructions per half -- left to the compiler the MFMAs came in dependent groups of
+    // three with the conversions between them, matrix pipe and VALU taking turns.  Here every MFMA is followed by its share
+    // of VALU work that does NOT depend on it, pinned with sched_barrier:
+    //   phase A   layer 1 of the NEXT unit        |  conversion of this unit's registers 0..7   (half 0)
+    //   phase B   layer 2, k-step (a, 0)          |  conversion of registers 8..15              (half 1)
+    //   phase C   layer 2, k-step (a, 1)          |  --
+    // (layer 1: T1 (W1 x + b1), three products in one accumulator, small terms first; conversion: ReLU and the cap as one
+    //  v_med3_f32 per value, hi = f16 toward zero, lo = f16(v - hi) >= 0.)
+    auto layer1 = [&](actor_f16v &d, const actor_u4 (&w)[FT], int c, auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const actor_h8 w1h = actor_as_h8(w[0]), w1l = actor_as_h8(w[1]);
+        if constexpr (k == 0) d = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1l, bxh[c], zero16, 0, 0, 0);
+        else if constexpr (k == 1) d = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, bxl[c], d, 0, 0, 0);
+        else d = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, bxh[c], d, 0, 0, 0);
+        asm volatile("" : "+v"(d));           // (pins the MFMA in program order: see layer2)
+    };
+    struct Conv { float v[8]; unsigned hh[4], hl[4]; };
+    // 16 atoms: 0..7 clamp value j, 8..11 pack pair j, 12..15 remainders of pair j
+    auto conv_atom = [&](Conv &cv, const actor_f16v &d, int half, auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k < 8) cv.v[k] = __builtin_amdgcn_fmed3f(d[8 * half + k], 0.0f, kActorCap);
+        else if constexpr (k < 12) cv.hh[k - 8] = actor_pk(cv.v[2 * (k - 8)], cv.v[2 * (k - 8) + 1]);
+        else cv.hl[k - 12] = actor_rem(cv.hh[k - 12], cv.v[2 * (k - 12)], cv.v[2 * (k - 12) + 1]);
+    };
+    auto layer2 = [&](const actor_u4 (&w)[FT], const Conv &cv, int c, int half, auto tc, auto kc) {
+        constexpr int t = decltype(tc)::value, k = decltype(kc)::value;
+        const actor_h8 bh = actor_as_h8((actor_u4){cv.hh[0], cv.hh[1], cv.hh[2], cv.hh[3]}), bl = actor_as_h8((actor_u4){cv.hl[0], cv.hl[1], cv.hl[2], cv.hl[3]});
+        const actor_h8 w2h = actor_as_h8(w[2 + 4 * t + 2 * half]), w2l = actor_as_h8(w[3 + 4 * t + 2 * half]);
+        if constexpr (k == 0) d2[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2l, bh, d2[t][c], 0, 0, 0);
+        else if constexpr (k == 1) d2[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h, bl, d2[t][c], 0, 0, 0);
+        else d2[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h, bh, d2[t][c], 0, 0, 0);
+        // (an MFMA is a pure value to the compiler and would sink to its only reader -- the end of the loop -- leaving the
+        //  conversions alone between the barriers; the empty statement pins it here)
+        asm volatile("" : "+v"(d2[t][c]));
+    };
+    // one unit: `dn` receives layer 1 of the next unit (fragments wn, column tile cn) while `dc` (this unit's) is converted
+    auto unit = [&](actor_f16v &dn, const actor_u4 (&wn)[FT], int cn, const actor_f16v &dc, const actor_u4 (&w)[FT], int c) {
+        Conv c0, c1;
+        actor_static_for<3>([&](auto kc) {                        // phase A
+            constexpr int k = decltype(kc)::value;
+            layer1(dn, wn, cn, kc);
+            actor_static_for<16>([&](auto ac) {
+                constexpr int q = decltype(ac)::value;
+                if constexpr (q >= (k == 0 ? 0 : k == 1 ? 6 : 11) && q < (k == 0 ? 6 : k == 1 ? 11 : 16)) conv_atom(c0, dc, 0, ac);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        actor_static_for<AT>([&](auto tc) {                       // phase B (the conversion of half 1 rides behind action tile 0's MFMAs)
+            actor_static_for<3>([&](auto kc) {
+                constexpr int k = decltype(kc)::value, t = decltype(tc)::value;
+                layer2(w, c0, c, 0, tc, kc);
+                if constexpr (t == 0)
+                    actor_static_for<16>([&](auto ac) {
+                        constexpr int q = decltype(ac)::value;
+                        if constexpr (q >= (k == 0 ? 0 : k == 1 ? 6 : 11) && q < (k == 0 ? 6 : k == 1 ? 11 : 16)) conv_atom(c1, dc, 1, ac);
+                    });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        actor_static_for<AT>([&](auto tc) {                       // phase C
+            actor_static_for<3>([&](auto kc) {
+                layer2(w, c1, c, 1, tc, kc);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+    };
+    actor_f16v da, db;                       // layer-1 accumulators of column tile 0 / 1 (they take turns)
+    actor_static_for<3>([&](auto kc) { layer1(da, wf, 0, kc); });
 #pragma unroll 1
     for (int a = 0; a < HT; ++a) {
         actor_u4 nx[FT];
-        const int an = a + 1 < HT ? a + 1 : a;          // (the last iteration re-requests its own tile: no branch around loads)
-#pragma unroll
+        const int an = a + 1 < HT ? a + 1 : a;          // (the last iteration re-requests its own tile: no branch around loads,
+#pragma unroll                                          //  and its look-ahead layer 1 lands in an accumulator nobody reads)
         for (int f = 0; f < FT; ++f) nx[f] = wl[((size_t)an * FT + f) * 64];
-        const actor_h8 w1h = actor_as_h8(wf[0]), w1l = actor_as_h8(wf[1]);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {         // column tile
-            // T1 (W1 x + b1), three products in one accumulator, small terms first
-            actor_f16v d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1l, bxh[c], zero16, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, bxl[c], d1, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, bxh[c], d1, 0, 0, 0);
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                // ReLU (and the cap) as one v_med3_f32 per value, hi = f16 toward zero, lo = f16(v - hi) >= 0
-                unsigned hh[4], hl[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v0 = __builtin_amdgcn_fmed3f(d1[8 * half + 2 * j], 0.0f, kActorCap);
-                    const float v1 = __builtin_amdgcn_fmed3f(d1[8 * half + 2 * j + 1], 0.0f, kActorCap);
-                    hh[j] = actor_pk(v0, v1);
-                    hl[j] = actor_rem(hh[j], v0, v1);
-                }
-                const actor_h8 bh = actor_as_h8((actor_u4){hh[0], hh[1], hh[2], hh[3]}), bl = actor_as_h8((actor_u4){hl[0], hl[1], hl[2], hl[3]});
-#pragma unroll
-                for (int t = 0; t < AT; ++t) {
-                    const actor_h8 w2h = actor_as_h8(wf[2 + 4 * t + 2 * half]), w2l = actor_as_h8(wf[3 + 4 * t + 2 * half]);
-                    d2[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2l, bh, d2[t][c], 0, 0, 0);
-                    d2[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h, bl, d2[t][c], 0, 0, 0);
-                    d2[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h, bh, d2[t][c], 0, 0, 0);
-                }
-            }
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        unit(db, wf, 1, da, wf, 0);
+        unit(da, nx, 0, db, wf, 1);
 #pragma unroll
         for (int f = 0; f < FT; ++f) wf[f] = nx[f];
     }

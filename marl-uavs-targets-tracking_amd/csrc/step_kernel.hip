@@ -503,9 +503,9 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     // v_readlane (a VALU instruction and a wait) wherever they are needed.  These variants run one or two wavefronts per
     // SIMD and use well under half of their vector registers: the constants that only ever feed per-lane arithmetic
     // move there for good.
-    // (not with the actor inside: its variant goes from 156 to 190 registers -- two wavefronts per SIMD instead of three -- and
-    //  a 200-step actor rollout from 2.30 to 2.66 ms; not in the 4-wave variants: no registers to spare at their occupancy)
-    constexpr bool kVConst = LONE && POLICY != kPolicyActor;
+    // (all single-wavefront variants, the actor one included since its matrix work moved to the 16-bit pipe: two
+    //  wavefronts per SIMD either way, 1.448 -> 1.424 ms per 200-step actor rollout; not the 4-wave variants: no registers to spare)
+    constexpr bool kVConst = LONE;
     StepParams p = p_in;
     if (kVConst) {
 #define UAVTRACK_V(f) p.f = vreg(p_in.f)
