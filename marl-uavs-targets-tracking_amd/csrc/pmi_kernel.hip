@@ -1047,7 +1047,12 @@ __global__ void __launch_bounds__(kMaxWorkgroup) pmi_mix_kernel(const MixParams 
     r = (1.0f - f.coop) * raw_i;                                       // uav.py:290
     if (SMALL) {
         const unsigned long long mask = (unsigned long long)me[0] | ((unsigned long long)me[1] << 32);
-        if (mask) {
+        if (mask && !(mask & (mask - 1))) {
+            // ONE neighbour: its softmax weight is exp(s - s) / exp(s - s) = 1 whatever the score (uav.py:287-288), so the score
+            // is not read -- and where both UAVs of a pair are each other's only neighbour the rollout kernel never emitted
+            // it (step_kernel.hip, drop_isolated).  fmaf(1, raw_j, 0) / 1 = raw_j: the same bits as the general form below.
+            r = fmaf(f.coop, __uint_as_float(env_rec[(size_t)(__ffsll((long long)mask) - 1) * RS + 3]), r);
+        } else if (mask) {
             auto slot_of = [&](int j) {                // where s_ij lives: emitted by the lower index
                 const int lo = j > i ? i : j, hi = j > i ? j : i;
                 const uint32_t *rl = env_rec + (size_t)lo * RS;

@@ -677,6 +677,17 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         }
     };
 
+    // An ISOLATED pair -- two UAVs that are each other's only neighbour -- needs no score: the softmax over a single
+    // neighbour is exactly 1 whatever s_ij is (uav.py:287-288), so both rewards are (1 - a) raw + a raw_partner and the mix
+    // kernel never reads the slot.  Such pairs are not emitted (a third of all pairs in the reference's 2000 m box).  `nball`:
+    // this UAV's neighbours, `later`: those with a higher index; the neighbours' set sizes were left in LDS ahead of the barrier.
+    auto drop_isolated = [&](unsigned long long nball, unsigned long long later) {
+        if (__popcll(nball) == 1 && later != 0ull &&
+            reinterpret_cast<const int *>(rawl)[e * (N + 1) + (__ffsll((long long)later) - 1)] == 1)
+            later = 0ull;
+        return later;
+    };
+
     // The single-wavefront plain rollout runs even and odd steps as two copies of the loop body: the table copy that is
     // "post-move" alternates with the step, so per copy every per-pair row address is a per-lane constant.
     // (an inner loop of constant trip count that is unrolled in full, not `#pragma unroll 2` on the step loop: a loop with
@@ -902,7 +913,9 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             tt = __builtin_amdgcn_fmed3f(acc.trk, 0.0f, p.tt_ceil) * p.inv_tt_ceil;
             if (!kSym) dupn = (__builtin_amdgcn_fmed3f(acc.dup * -0.5f, p.dup_floor, 0.0f) - p.dup_floor) * p.inv_dup - 1.0f;
             if (!kSym) raw = p.alpha * tt + p.beta * bp + p.gamma * dupn;      // (kSym: behind the barrier, once the partners' halves are in)
-            if (MODE != UAVTRACK_REWARD_RAW) rawl[e * (N + 1) + i] = raw;
+            if (MODE == UAVTRACK_REWARD_MEAN) rawl[e * (N + 1) + i] = raw;
+            // MAAC-R: the size of this UAV's neighbour set, for its neighbours to see behind the barrier (isolated pairs, below)
+            if (MODE == UAVTRACK_REWARD_PMI && kMask) reinterpret_cast<int *>(rawl)[e * (N + 1) + i] = __popcll(nbmask & ~(1ull << i));
         }
         if (kPipeEmit && tid == 0) {
             // MAAC-R: the reservation made a step ago is taken HERE, ahead of this step's output stores -- its wait
@@ -1011,7 +1024,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             unsigned long long nball = 0, later = 0;        // all neighbours / neighbours j > i
             if (active) {
                 nball = nbmask & ~(1ull << i);
-                later = (i + 1 < 64) ? (nball >> (i + 1)) << (i + 1) : 0ull;
+                later = drop_isolated(nball, (i + 1 < 64) ? (nball >> (i + 1)) << (i + 1) : 0ull);
                 mine = __popcll(later);
                 if (mine) slot = (int)atomicAdd(&wg_cnt[0], (unsigned)mine);
             }
@@ -1077,7 +1090,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             unsigned long long nball = 0, later = 0;        // all neighbours / neighbours j > i
             if (active) {
                 nball = nbmask & ~(1ull << i);
-                later = (i + 1 < 64) ? (nball >> (i + 1)) << (i + 1) : 0ull;
+                later = drop_isolated(nball, (i + 1 < 64) ? (nball >> (i + 1)) << (i + 1) : 0ull);
                 mine = __popcll(later);
                 if (mine) slot = (int)atomicAdd(&wg_cnt[0], (unsigned)mine);
             }
@@ -1088,7 +1101,6 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         if (MODE == UAVTRACK_REWARD_PMI) {
             unsigned *wg_cnt = covw + 2 * E * CW;          // two extra words behind the coverage masks
             if (tid == 0) wg_cnt[0] = 0;
-            __syncthreads();
             // One record per agent-step for the mix kernel (internal.h, nbrec_words): the neighbour mask, where this
             // UAV's pairs start in the pair list (their scores land in the same slots), and the raw reward.
             const int W = nbrec_mask_words(N);
@@ -1100,14 +1112,14 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                 if (Z3) { const float dz = nw.z - z; d2 = fmaf(dz, dz, d2); }
                 return j != i && d2 <= p.dp2;
             };
+            if (active && N <= 64) {                        // (the post-move table is stable from the P2 barrier to the next step's P1)
+                for (int j = 0; j < N; ++j) nball |= (unsigned long long)(is_neighbour(j) ? 1u : 0u) << j;
+                reinterpret_cast<int *>(rawl)[e * (N + 1) + i] = __popcll(nball);      // for drop_isolated
+            }
+            __syncthreads();
             if (active) {
-                if (kMask) {
-                    nball = nbmask & ~(1ull << i);
-                } else if (N <= 64) {
-                    for (int j = 0; j < N; ++j) nball |= (unsigned long long)(is_neighbour(j) ? 1u : 0u) << j;
-                }
                 if (N <= 64) {
-                    later = (i + 1 < 64) ? (nball >> (i + 1)) << (i + 1) : 0ull;
+                    later = drop_isolated(nball, (i + 1 < 64) ? (nball >> (i + 1)) << (i + 1) : 0ull);
                     mine = __popcll(later);
                 } else {
                     for (int j = i + 1; j < N; ++j) mine += is_neighbour(j) ? 1 : 0;

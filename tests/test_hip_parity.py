@@ -1005,11 +1005,11 @@ def test_bench_contract_line(uavtrack):
         assert r2["launches_timed"] >= 10 and r2["launches_untimed_before"] >= 3 and 0.0 < r2["frac"] < 1.0
         if key.startswith("configs[2]"):
             assert r2["bound"] == "mfma" and r2["unit"] == "TFLOP/s" and r2["peak"] == 2500.0 and "pmi_score_t3_kernel" in r2["kernel"]
-            assert 0.1 < r2["pairs_per_agent_step"] < 1.0 and r2["scorer_ms_per_launch"] < r2["avg_launch_ms"]
+            assert 0.05 < r2["pairs_per_agent_step"] < 1.0 and r2["scorer_ms_per_launch"] < r2["avg_launch_ms"]
             assert r2["fp32_equivalent_over_fp32_mfma_peak"] > 1.0          # past what the fp32 matrix pipe could do at all
             assert c["agent_steps_per_s"] > (6e9 if "H64" in key else 2.5e9 if "dense" in key else 4e9)     # sanity floors (round 3: 13.6-14 / 5.4-5.6 / 9.2-9.6 G)
             assert r2["rescored_chunks"] == 0
-            assert (r2["pairs_per_agent_step"] > 0.4) == ("dense" in key)
+            assert (r2["pairs_per_agent_step"] > 0.3) == ("dense" in key)      # scored pairs: isolated pairs are not emitted
         else:
             assert r2["bound"] == "hbm" and abs(r2["algorithmic_bytes_per_agent_step"] - 124.1) < 1e-9
             assert r2["agent_steps_per_launch"] == 8192 * 50 * 200 and r2["frac"] > 0.15
