@@ -546,7 +546,9 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     unsigned *rstw = covw + 2 * E * CW + 2;              // [E] 0, or 1 + the episode number an environment is being reset to
     float *climb_l = reinterpret_cast<float *>(rstw + E); // (3-D) [2][UAVTRACK_MAX_CLIMB] cos / sin of the climb angles
     // symmetric duplicate term (MAAC reward mode, sym_dup): [E][x | y | (z) | 2 N accumulators]
-    constexpr bool kSym = MODE == UAVTRACK_REWARD_RAW;
+    // (MAAC and MAAC-R: the raw reward is needed only behind the second barrier -- in the output, in the neighbour record;
+    //  MAAC-G reads its neighbours' raw rewards there and would need a third barrier)
+    constexpr bool kSym = MODE != UAVTRACK_REWARD_MEAN;
     float *symbase = climb_l + (Z3 ? 2 * UAVTRACK_MAX_CLIMB : 0);
     const int symlen = sym_pose_len(N), symstride = sym_words(N, Z3);
 
@@ -654,7 +656,8 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     constexpr bool kPipeEmit = MODE == UAVTRACK_REWARD_PMI && N_ > 0 && N_ <= 64 && !LONE;
     constexpr unsigned kPoolBlock = 64;
     unsigned pool_base = 0, pool_left = 0, pend_size = 0, pend_base_v = 0, real_pairs = 0;   // (wave-uniform but for pend_base_v: lane 0's)
-    bool pend = false;
+    bool pend = false, pend_got = false;      // a block has been asked for / its base has been collected into pend_base_s
+    unsigned pend_base_s = 0;
     auto pool_dummies = [&](unsigned base, unsigned n) {
         for (unsigned k = (unsigned)tid; k < n; k += (unsigned)nthreads) p.pairs[base + k] = make_uint2(0xFFFFFFFFu, 0u);
     };
@@ -926,6 +929,13 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         }
         UAVTRACK_STEP_BARRIER();
 
+        // (MAAC-R slot pool) a block asked for at an earlier step is collected HERE, ahead of this step's output stores: the
+        // wait for the returning atomic drains the vector-memory counter, and behind the stores it would wait for all of them
+        if (kPoolEmit && pend && !pend_got) {
+            pend_base_s = (unsigned)__builtin_amdgcn_readfirstlane((int)pend_base_v);
+            pend_got = true;
+        }
+
         // ---- P4: cooperative reward, coverage, outputs
         if (active) {
             if (kSym) {      // duplicate term: own half + what the partners added to this UAV's two accumulator entries
@@ -1048,18 +1058,20 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                 const unsigned moved = (unsigned)__builtin_amdgcn_readfirstlane((int)wg_cnt[1]), cut = total - moved;
                 pool_dummies(pool_base + cut, pool_left - cut);
                 if (pend && pend_size < moved) {            // (a step far above the recent ones: the block asked for is too small as well)
-                    pool_dummies((unsigned)__builtin_amdgcn_readfirstlane((int)pend_base_v), pend_size);
+                    pool_dummies(pend_got ? pend_base_s : (unsigned)__builtin_amdgcn_readfirstlane((int)pend_base_v), pend_size);
                     pend = false;
                 }
                 if (!pend) {     // (the launch's last step takes exactly what it needs: nothing left over to fill with dummies)
                     pend_size = (moved > kPoolBlock || t + 1 == p.T) ? moved : kPoolBlock;
                     if (tid == 0) pend_base_v = atomicAdd(p.pair_count, pend_size);
+                    pend_got = false;
                 }
-                const unsigned nbase = (unsigned)__builtin_amdgcn_readfirstlane((int)pend_base_v);   // (waits for the reservation: as a rule made a step or more ago)
+                // (as a rule the block was asked for a step or more ago and collected at the top of this step's P4; else wait here)
+                const unsigned nbase = pend_got ? pend_base_s : (unsigned)__builtin_amdgcn_readfirstlane((int)pend_base_v);
                 if (!fits) first = nbase + ((unsigned)slot - cut);
                 pool_base = nbase + moved;
                 pool_left = pend_size - moved;
-                pend = false;
+                pend = false; pend_got = false;
             } else {
                 pool_base += total;
                 pool_left -= total;
@@ -1078,7 +1090,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             if (!pend && pool_left < 2 * total && t + 2 < p.T) {   // about to run dry: ask for the next block now, collect it later
                 pend_size = 4 * total > kPoolBlock ? 4 * total : kPoolBlock;
                 if (tid == 0) pend_base_v = atomicAdd(p.pair_count, pend_size);
-                pend = true;
+                pend = true; pend_got = false;
             }
         } else
         if (kPipeEmit) {
@@ -1214,7 +1226,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     }
     if (kPoolEmit) {                         // what the pool and an uncollected block have left
         pool_dummies(pool_base, pool_left);
-        if (pend) pool_dummies((unsigned)__builtin_amdgcn_readfirstlane((int)pend_base_v), pend_size);
+        if (pend) pool_dummies(pend_got ? pend_base_s : (unsigned)__builtin_amdgcn_readfirstlane((int)pend_base_v), pend_size);
     }
     if (MODE == UAVTRACK_REWARD_PMI && tid == 0 && real_pairs && p.pair_total)      // accounting (uavtrack_pmi_pairs_scored)
         atomicAdd(p.pair_total, (unsigned long long)real_pairs);
@@ -1286,13 +1298,13 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     }
 }
 
-// (the symmetric duplicate term's pose arrays and accumulators exist in the MAAC reward mode only: kSym)
+// (the symmetric duplicate term's pose arrays and accumulators exist in the MAAC and MAAC-R reward modes: kSym)
 size_t lds_bytes_for(int E, int N, int M, bool z3, int reward_mode)
 {
     const size_t CW = cov_words(M), MP = pairs_of(M);
     const size_t f4 = (size_t)E * ustride_of(N) + (size_t)E * tstride_of(M);
     const size_t f = (size_t)E * M + (size_t)E * (N + 1) + (z3 ? (size_t)E * MP * 2 : 0) + (size_t)E * M + 2 * E * CW + 2 + E +
-                     (z3 ? 2 * UAVTRACK_MAX_CLIMB : 0) + (reward_mode == UAVTRACK_REWARD_RAW ? (size_t)E * sym_words(N, z3) : 0);
+                     (z3 ? 2 * UAVTRACK_MAX_CLIMB : 0) + (reward_mode != UAVTRACK_REWARD_MEAN ? (size_t)E * sym_words(N, z3) : 0);
     return (f4 * 16 + f * 4 + 15) & ~(size_t)15;   // ustride >= 3 N float4 per env, so ep_sums staging (E N float4) fits
 }
 
