@@ -227,9 +227,9 @@ void fold_constants(const uavtrack_config &c, StepParams &p, float *climb_c, flo
     const double log2e = 1.4426950408889634;
     p.exp_k0 = (float)log2e;
     p.exp_k1 = (float)(log2e / (2.0 * c.dp));
-    {   // sym_dup accumulates g * 2^b in 32-bit integers: N terms of at most e each must stay below 2^31
-        int b = 31;
-        while (std::ldexp(3.0 * c.n_uav, b) >= 2147483648.0 && b > 0) --b;
+    {   // sym_dup (step_kernel.hip) accumulates round(g * 2^b) as the low mantissa bits of 1.5 * 2^23 + g * 2^b: each term
+        // (at most e * 2^b) must stay below 2^22, and n_uav of them below 2^32
+        const int b = kSymBits;
         p.sym_k0 = (float)(log2e + b);
         p.sym_inv = std::ldexp(1.0f, -b);
     }

@@ -14,6 +14,7 @@ namespace uavtrack {
 constexpr float kPi = 3.14159265358979323846f;
 constexpr float kTwoPi = 6.28318530717958647692f;
 constexpr int kMaxWorkgroup = 512;   // __launch_bounds__ of the rollout kernel
+constexpr int kSymBits = 20;         // fixed-point bits of the shared duplicate term (step_kernel.hip, sym_dup): e * 2^20 < 2^22
 
 // Kernel arguments of one rollout launch (T >= 1 steps).  All pointers are device
 // pointers.  Derived constants are computed once on the host in fp64, then cast.
@@ -96,7 +97,7 @@ struct StepParams {
     float inv_na;                // 1 / na: the climb index of a 3-D action is floor((a + 0.5) / na)
     float act_bias, inv_act_bias;   // step_kernel.hip act_bias_shape(): K, a power of two above n_uav * na * nc, and 1 / K
     float exp_k0, exp_k1;        // exp((2dp-d)/(2dp)) = exp2(k0 - k1*d)   (uav.py:226)
-    float sym_k0, sym_inv;       // step_kernel.hip sym_dup: k0 + b and 2^-b, b the fixed-point bits of the shared duplicate term
+    float sym_k0, sym_inv;       // step_kernel.hip sym_dup: k0 + b and 2^-b, b = kSymBits the fixed-point bits of the shared duplicate term
     float tt_ceil, inv_tt_ceil;  // 2*m_targets                   (environment.py:208)
     float dup_floor, inv_dup;    // -e/2*n_uav and 1/(e/2*n_uav)  (environment.py:210)
     float alpha, beta, gamma, coop;

@@ -60,6 +60,7 @@ struct Acc {
     float dup;   // uav.py:214-229
 };
 
+constexpr float kSymMagic = 12582912.0f;   // 1.5 * 2^23 = 0x4B400000
 constexpr float kFar = 1.0e18f;   // padding agent of an odd-sized pair: every range test fails, 0 * kFar = 0
 
 __device__ __forceinline__ float fast_sqrt(float v) { return __builtin_amdgcn_sqrtf(v); }
@@ -228,7 +229,8 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
                                            unsigned *__restrict__ covw, int covbase,
                                            float xi, float yi, float zi, float ci, float si, float ai,
                                            float xo, float yo, float zo, float co, float so, float ao, Acc &a,
-                                           unsigned long long &nbmask, const float4 *const *__restrict__ rsel = nullptr)
+                                           unsigned long long &nbmask, const float4 *const *__restrict__ rsel = nullptr,
+                                           const float4 *__restrict__ ubase = nullptr, unsigned copyw = 0)   // (copy_row)
 {
     const v2f xi2 = splat(xi), yi2 = splat(yi), zi2 = splat(zi);
     const v2f nscale = splat(p.le_neg_scale);
@@ -252,8 +254,16 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
     // rsel (single-wavefront headline variant, even / odd steps as two copies of the step loop): the selected copy's row
     // base per pair, computed once per launch -- which copy is post-move alternates with the step, the choice per pair and
     // lane does not
+    // The copy of pair jp this lane reads (one select serves pose, heading, action and z).  Up to 32 pairs the choice comes
+    // from a per-lane bit word (copyw: bit jp = which copy holds what this lane sees of pair jp, this step): a bit-field
+    // extract and a multiply-add on the row address, one instruction less than compare + select + add.
+    auto copy_row = [&](int jp) -> const float4 * {
+        if constexpr (N_ > 0 && N_ <= 64)       // (every caller of a specialised shape passes ubase and copyw)
+            return reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(ubase) + __builtin_amdgcn_ubfe(copyw, (unsigned)jp, 1u) * 48u);
+        return (2 * jp < i) ? rowNew : rowOld;
+    };
     auto fetch_row = [&](int jq) {
-        const float4 *rq = rsel ? rsel[jq] : ((2 * jq < i) ? rowNew : rowOld);
+        const float4 *rq = rsel ? rsel[jq] : copy_row(jq);
         PN0[jq] = rowNew[jq * 6]; PM0[jq] = rq[jq * 6]; PM1[jq] = rq[jq * 6 + 1];
         PM2[jq] = *reinterpret_cast<const v2f *>(&rq[jq * 6 + 2]);
     };
@@ -297,16 +307,23 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
     v2f sa = splat(0.f), dup = splat(0.f);
     constexpr bool NBF = NB && N_ > 0 && (N_ + 1) / 2 <= kCovPairs;
     v2f nbf = splat(0.f);
+    const float4 *ub = ubase;
 #pragma unroll UU
     for (int jp = 0; jp < NP; ++jp) {
-        const float4 *rs = (rsel && kPrefetch) ? rsel[kPrefetch ? jp : 0] : ((2 * jp < i) ? rowNew : rowOld);   // one select serves pose, heading, action, z
+        // (the row of pair jp in the copy this lane reads; with the bit word the pair's offset rides in a pointer that is
+        //  bumped per pair -- after unrolling: immediate offsets and one add per loop body, not one per pair)
+        const float4 *rp;
+        if (rsel && kPrefetch) rp = rsel[kPrefetch ? jp : 0] + jp * 6;
+        else if constexpr (N_ > 0 && N_ <= 64) rp = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(ub) + __builtin_amdgcn_ubfe(copyw, (unsigned)jp, 1u) * 48u);
+        else rp = copy_row(jp) + jp * 6;
+        ub += 6;
         if (kPrefetch) {
             if (jp + PF < NP) fetch_row(jp + PF);
             __builtin_amdgcn_sched_barrier(0x407);
         }
         const float4 n0 = kPrefetch ? PN0[kPrefetch ? jp : 0] : rowNew[jp * 6];
-        const float4 m0 = kPrefetch ? PM0[kPrefetch ? jp : 0] : rs[jp * 6], m1 = kPrefetch ? PM1[kPrefetch ? jp : 0] : rs[jp * 6 + 1];
-        const float4 m2 = kPrefetch ? make_float4(PM2[kPrefetch ? jp : 0].x, PM2[kPrefetch ? jp : 0].y, 0.f, 0.f) : rs[jp * 6 + 2];
+        const float4 m0 = kPrefetch ? PM0[kPrefetch ? jp : 0] : rp[0], m1 = kPrefetch ? PM1[kPrefetch ? jp : 0] : rp[1];
+        const float4 m2 = kPrefetch ? make_float4(PM2[kPrefetch ? jp : 0].x, PM2[kPrefetch ? jp : 0].y, 0.f, 0.f) : rp[2];
         const v2f dxn = (v2f){n0.x, n0.y} - xi2, dyn = (v2f){n0.z, n0.w} - yi2;
         const v2f dxm = (v2f){m0.x, m0.y} - xi2, dym = (v2f){m0.z, m0.w} - yi2;
         v2f d2n = pk_fma(dyn, dyn, dxn * dxn), d2m = pk_fma(dym, dym, dxm * dxm);
@@ -364,9 +381,9 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
 // The duplicate-tracking term (uav.py:214-229) is symmetric on the post-move poses: g(d_ij) enters UAV i's sum and UAV j's.
 // Each lane evaluates only the peers i + 1 .. i + N/2 (cyclically: a balanced half of the pair matrix), adds the value to its
 // own running sum and, through the LDS, to the partner's accumulator -- half the square roots and exponentials of the full
-// sweep.  The accumulators are FIXED-POINT integers (g * 2^sym_bits, at most e * N * 2^sym_bits < 2^32): integer addition
+// sweep.  The accumulators are FIXED-POINT integers (g * 2^kSymBits, at most e * N * 2^kSymBits < 2^32): integer addition
 // commutes, so the LDS atomics leave the same bits whatever order the wavefronts arrive in (a float accumulation would
-// not), and the quantisation (2^-22 per term at N = 50) is far below the fp32 rounding of the sum it replaces.  The
+// not), and the quantisation (2^-21 per term) is below the fp32 rounding of the sum it replaces.  The
 // accumulator array has 2 N entries: lane i adds to entry i + k without wrapping and reads entries i and i + N.
 // Even N: the opposite peer (k = N/2) is evaluated by both ends, each keeping it for itself.
 template <int N_, bool Z3, bool VC = false>
@@ -390,8 +407,10 @@ __device__ __forceinline__ unsigned sym_dup(const StepParams &p, int N, int i, c
         v2f d2 = pk_fma(dy, dy, dx * dx);
         if (Z3) { const v2f dz = q.z - zi2; d2 = pk_fma(dz, dz, d2); }
         const v2f w = pk_fma((v2f){fast_sqrt(d2.x), fast_sqrt(d2.y)}, splat(-p.exp_k1), splat(p.sym_k0));
-        const v2f g = pk_le_mask<VC>(d2, nscale, p.le_two_dp2) * (v2f){fast_exp2(w.x), fast_exp2(w.y)};
-        return make_uint2((unsigned)g.x, (unsigned)g.y);
+        // float -> fixed point inside the FMA that applies the mask: 1.5 * 2^23 + v holds round(v) in its low mantissa bits
+        // (0 <= v < 2^22), and the integer sums carry kSymMagic once per term -- N - 1 terms per UAV, taken off at the end
+        const v2f g = pk_fma(pk_le_mask<VC>(d2, nscale, p.le_two_dp2), (v2f){fast_exp2(w.x), fast_exp2(w.y)}, splat(kSymMagic));
+        return make_uint2(__float_as_uint(g.x), __float_as_uint(g.y));
     };
     // (the poses of the next two peers are requested before the current two are evaluated: the LDS round trip, the
     // square roots and the exponentials of consecutive iterations overlap)
@@ -705,6 +724,9 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             selB[jq] = (2 * jq < i) ? uenv + 3 : uenv;
         }
     }
+    // sequential view as a bit word: bit jp set = this lane sees pair jp BEFORE its move (2 jp >= i); the copy that holds it
+    // is pn ^ bit (sweep_fast, copyw)
+    const unsigned oldw = (i + 1) / 2 < 32 ? ~0u << ((i + 1) / 2) : 0u;
     for (int t0 = 0; t0 < p.T; t0 += kStepsPerIter) {
 #pragma unroll
     for (int tpar = 0; tpar < kStepsPerIter; ++tpar) {
@@ -881,7 +903,8 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             } else {
                 sweep_fast<N_, M_, Z3, kMask, kPrefetchRows, kSym, kVConst>(p, N, M, i, rowNew, rowOld, tenv, tzrow, covw, cbuf + e * CW,
                                               x, y, z, c, s, ai, xo, yo, zo, co, so, ao, acc, nbmask,
-                                              kStepsPerIter == 2 ? (tpar == 0 ? selA : selB) : nullptr);   // (pn == tpar: t0 is even)
+                                              kStepsPerIter == 2 ? (tpar == 0 ? selA : selB) : nullptr,   // (pn == tpar: t0 is even)
+                                              uenv, pn ? ~oldw : oldw);
             }
             if (kSym) {      // every active lane, whichever sweep it took: its partners count on its half of the pairs
                 const float *sp = symbase + e * symstride;
@@ -940,7 +963,8 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         if (active) {
             if (kSym) {      // duplicate term: own half + what the partners added to this UAV's two accumulator entries
                 const unsigned *dq = reinterpret_cast<const unsigned *>(symbase + e * symstride + (Z3 ? 3 : 2) * symlen);
-                const float dsum = (float)(sym_own + dq[i] + dq[N + i]) * p.sym_inv;
+                // (every UAV's three sums hold N - 1 terms between them: its own half and one from each partner)
+                const float dsum = (float)(sym_own + dq[i] + dq[N + i] - (unsigned)(N - 1) * 0x4B400000u) * p.sym_inv;
                 dupn = (__builtin_amdgcn_fmed3f(dsum * -0.5f, p.dup_floor, 0.0f) - p.dup_floor) * p.inv_dup - 1.0f;
                 raw = p.alpha * tt + p.beta * bp + p.gamma * dupn;
             }
