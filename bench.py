@@ -714,6 +714,33 @@ def extras(uavtrack, args, B, device, bytes_unit):
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     cl["actor_fused"] = {"agent_steps_per_s": B * N * 1000 / dt, "ms_per_step": dt * 1e3 / 1000}
+    # what bounds it: the policy's two layers are 72 v_mfma_f32_32x32x16_f16 per wavefront-step (csrc/actor.h: three f16
+    # products per fp32 product, H = 128) beside the step kernel's vector work -- priced against the dense 16-bit MFMA roof in
+    # executed flops, and against HBM by the algorithmic bytes of the step (the action is produced in the kernel: no 4-byte read)
+    info = env.launch_info()
+    waves = info["workgroups"] * (info["workgroup"] // 64)
+    mfma_flops = 72 * 2 * 32 * 32 * 16 * waves * 1000
+    hbm_bytes = (bytes_unit - 4) * B * N * 1000
+    cl["actor_fused"]["roofline"] = {
+        "bound": "mfma", "achieved": mfma_flops / dt / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": mfma_flops / dt / 1e12 / BF16_MFMA_PEAK_TFLOPS, "mfma_per_wavefront_step": 72, "wavefronts": waves,
+        "hbm_frac": hbm_bytes / dt / 1e9 / HBM_PEAK_GBS,
+        "note": "neither roof binds: the launch is bound by vector-instruction issue beside the MFMAs (profiles/r04actor_summary.md)"}
+    env.close()
+    # the paper's method end to end on the device: the same fused actor rollout under the MAAC-R reward (configs[2])
+    import copy
+    a2 = copy.copy(args)
+    a2.reward, a2.cooperative, a2.pmi_hidden = "pmi", 0.3, 128
+    env = make_env(uavtrack, a2, B, device)
+    env.set_actor(actor)
+    res = env.run_actor(200, env.reset(seed=args.seed), seed=args.seed, want_terms=False)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        res = env.run_actor(200, env.reset(seed=args.seed), seed=args.seed, want_terms=False, out=res)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    cl["actor_fused_maac_r"] = {"agent_steps_per_s": B * N * 1000 / dt, "ms_per_step": dt * 1e3 / 1000}
     env.close()
     if VERBOSE:
       cl["note"] = ("reference-shaped shared actor (FnnPolicyNet 12-128-12 softmax as in configs/MAAC.yaml, random "
