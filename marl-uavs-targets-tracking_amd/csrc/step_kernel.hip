@@ -274,8 +274,10 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
         for (int jq = 0; jq < PF && jq < QN; ++jq) fetch_row(jq);
         __builtin_amdgcn_sched_barrier(0x407);
     }
-#pragma unroll UAVTRACK_UNROLL_T
-    for (int kp = 0; kp < MP; ++kp) {
+    // One coverage word (12 target pairs) at a time: an inner loop of constant trip count that unrolls without a
+    // remainder, and the flush of the word's bits behind it (a `kp % 12` test inside a partially unrolled loop cost a scalar
+    // division and a branch per pair, and cut the sweep into one basic block per pair).
+    auto target_pair = [&](int kp) {
         const float4 q0 = kPrefetch ? Q0[kPrefetch ? kp : 0] : trow[kp * 2], q1 = kPrefetch ? Q1[kPrefetch ? kp : 0] : trow[kp * 2 + 1];
         const v2f dx = (v2f){q0.x, q0.y} - xi2, dy = (v2f){q0.z, q0.w} - yi2;
         v2f d2 = pk_fma(dy, dy, dx * dx);
@@ -289,10 +291,28 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
         cnt += mm;
         trk = pk_fma(mm, dist, trk);                 // sum m d: tracking reward sum m (1 + (dp - d)/dp) = 2 cnt - (sum m d)/dp
         cov = pk_fma(cov, splat(4.0f), pk_le_mask<VC>(d2, nscale, p.lt_dp2));
-        if (kp % kCovPairs == kCovPairs - 1 || kp == MP - 1) {       // 12 digits < 2^24: exact in fp32
-            const unsigned bits = (unsigned)cov.x | ((unsigned)cov.y << 1);
-            if (bits) atomicOr(&covw[covbase + kp / kCovPairs], bits);
-            cov = splat(0.f);
+    };
+    auto flush_word = [&](int w) {                   // 12 digits < 2^24: exact in fp32
+        const unsigned bits = (unsigned)cov.x | ((unsigned)cov.y << 1);
+        if (bits) atomicOr(&covw[covbase + w], bits);
+        cov = splat(0.f);
+    };
+    if constexpr (M_ > 0) {
+        constexpr int MPc = (M_ + 1) / 2, CWc = (MPc + kCovPairs - 1) / kCovPairs;
+#pragma unroll
+        for (int w = 0; w < CWc; ++w) {
+            constexpr int kInner = MPc <= UAVTRACK_UNROLL_T ? MPc : 6;      // (12 = 2 x 6; a last word shorter than 6 unrolls in full)
+            const int k1 = (w + 1) * kCovPairs < MPc ? (w + 1) * kCovPairs : MPc;
+#pragma unroll kInner
+            for (int kp = w * kCovPairs; kp < k1; ++kp) target_pair(kp);
+            flush_word(w);
+        }
+    } else {
+        for (int w = 0; w * kCovPairs < MP; ++w) {
+            const int k1 = min((w + 1) * kCovPairs, MP);
+#pragma unroll 4
+            for (int kp = w * kCovPairs; kp < k1; ++kp) target_pair(kp);
+            flush_word(w);
         }
     }
     a.cntT = cnt.x + cnt.y; a.iwT = a.cntT;
