@@ -105,10 +105,11 @@ struct StepParams {
 
 // MAAC-R neighbour record of one agent-step, 32-bit words: [0 .. W) neighbour bit mask (d <= dp on post-move poses,
 // uav.py:278; bit j = UAV j, self excluded), [W] index of the first pair this UAV emitted (its neighbours j > i, in
-// ascending j, occupy consecutive slots of the pair list / score array), [W + 1] raw reward (float bits).
-// W = 2 up to 64 UAVs (one 16-byte record), else ceil(N / 32).
-__host__ __device__ inline int nbrec_mask_words(int N) { return N <= 64 ? 2 : (N + 31) / 32; }
-__host__ __device__ inline int nbrec_words(int N) { return nbrec_mask_words(N) + 2; }
+// ascending j, occupy consecutive slots of the pair list / score array; isolated pairs are not emitted).  W = 1 up to 32
+// UAVs (one 8-byte record), 2 up to 64, else ceil(N / 32).  The UAV's raw reward travels in the REWARD output slot of the
+// step (step_kernel.hip, pmi_reward_slot): raw while it has neighbours, the final reward when it has none.
+__host__ __device__ inline int nbrec_mask_words(int N) { return N <= 32 ? 1 : (N <= 64 ? 2 : (N + 31) / 32); }
+__host__ __device__ inline int nbrec_words(int N) { return nbrec_mask_words(N) + 1; }
 
 struct PmiWeights {
     float *blob = nullptr;   // device, folded layout of uavtrack_set_pmi_weights; behind it the bf16 planes of fc1

@@ -1005,9 +1005,9 @@ __global__ void __launch_bounds__(H * 2, 1) pmi_score_t3_kernel(const PmiParams 
 }
 
 struct MixParams {
-    const uint32_t *nbrec;       // [S][B][N][W + 2] neighbour records of the chunk's S steps
-    const float *scores;         // one per pair
-    float *reward;               // [S][B][N]
+    const uint32_t *nbrec;       // [S][B][N][W + 1] neighbour records of the chunk's S steps (internal.h, nbrec_words)
+    const float *scores;         // one per emitted pair
+    float *reward;               // [S][B][N]: in, what the rollout kernel left (raw reward of a UAV with neighbours, final reward of one without); out, final
     float *rsum;                 // [S][B] mean over the UAVs of the final reward (nullable): what the episode sum adds up
     unsigned *pair_count;        // reset here for the next chunk's pair emission
     unsigned *flags;             // [0] the scorer's f16 range flag, cleared here; [1] chunks the wide-range kernel re-scored so far
@@ -1015,61 +1015,97 @@ struct MixParams {
     float coop;
 };
 
-// One lane per UAV-step, E whole (step, environment) instances per workgroup.  The instances' records are staged
-// in LDS; a lane walks the set bits of its own mask twice (max, then exp-sum) and reads one score per neighbour.
-template <bool SMALL>            // SMALL: N <= 64, 16-byte records, 64-bit mask arithmetic
+// One lane per UAV-step, E whole (step, environment) instances per workgroup.  The instances' records and reward slots are
+// staged in LDS; a lane with neighbours walks the set bits of its own mask twice (max, then exp-sum), reads one score per
+// neighbour and rewrites its reward slot; a lane without neighbours found its final reward there and touches nothing.
+constexpr int mix_batch(int ws) { return ws ? 4 : 1; }     // (2: 0.130, 4: 0.114, 8: 0.123, 16: 0.181 ms per 200 steps at 4096 x 20)     // instance groups per workgroup (swarms up to 64 UAVs): their loads are all in flight before the first is used
+template <int WS>                // mask words of a record when N <= 64 (1: N <= 32, 2: N <= 64), 0: any N (word loops)
 __global__ void __launch_bounds__(kMaxWorkgroup) pmi_mix_kernel(const MixParams f)
 {
     extern __shared__ uint32_t mix_lds[];
+    constexpr int kMixBatch = mix_batch(WS);
     const int tid = threadIdx.x;
     const int N = f.N;
-    const int W = SMALL ? 2 : nbrec_mask_words(N), RS = W + 2;
-    const int env0 = blockIdx.x * f.E;
-    const int envs_here = min(f.E, f.SB - env0);
+    const int W = WS ? WS : nbrec_mask_words(N), RS = W + 1;
+    const int EN = f.E * N;                                 // lanes of one instance group
     const int e = tid / N, i = tid - e * N;
-    const bool active = tid < f.E * N && e < envs_here;
-    const size_t gid = (size_t)(env0 + e) * N + i;
+    float *rv = reinterpret_cast<float *>(mix_lds + (size_t)kMixBatch * EN * RS);      // the reward slots as the rollout kernel left them
     if (blockIdx.x == 0 && tid == 0) {
         *f.pair_count = 0;
         if (f.flags[0]) { f.flags[0] = 0; f.flags[1] += 1; }
     }
-    if (active) {
-        if (SMALL) reinterpret_cast<uint4 *>(mix_lds)[tid] = reinterpret_cast<const uint4 *>(f.nbrec)[gid];
-        else
-            for (int w = 0; w < RS; ++w) mix_lds[(size_t)tid * RS + w] = f.nbrec[gid * RS + w];
+    // A workgroup takes kMixBatch consecutive groups of E instances (a group of one or a few instances per pass over the
+    // lanes): with one group per workgroup the launch was bound by workgroup turnover (270 000 single-wavefront groups of
+    // two dependent memory trips each), not by its 13 bytes per UAV-step.
+    bool active[kMixBatch];
+    size_t gid[kMixBatch];
+#pragma unroll
+    for (int k = 0; k < kMixBatch; ++k) {
+        const int env0 = (blockIdx.x * kMixBatch + k) * f.E;
+        active[k] = tid < EN && env0 + e < f.SB;
+        gid[k] = (size_t)(env0 + e) * N + i;
+    }
+    {   // every load of the batch in flight, then the stores to LDS
+        uint2 rec2[kMixBatch];
+        float rw[kMixBatch];
+#pragma unroll
+        for (int k = 0; k < kMixBatch; ++k)
+            if (active[k]) {
+                if (WS == 1) rec2[k] = reinterpret_cast<const uint2 *>(f.nbrec)[gid[k]];
+                rw[k] = f.reward[gid[k]];
+            }
+#pragma unroll
+        for (int k = 0; k < kMixBatch; ++k)
+            if (active[k]) {
+                if (WS == 1) reinterpret_cast<uint2 *>(mix_lds)[k * EN + tid] = rec2[k];
+                else
+                    for (int w = 0; w < RS; ++w) mix_lds[(size_t)(k * EN + tid) * RS + w] = f.nbrec[gid[k] * RS + w];
+                rv[k * EN + tid] = rw[k];
+            }
     }
     __syncthreads();
-    float r = 0.0f;
-    if (active) {
-    const uint32_t *env_rec = mix_lds + (size_t)e * N * RS;
+    float r[kMixBatch];
+#pragma unroll
+    for (int k = 0; k < kMixBatch; ++k) {
+    r[k] = 0.0f;
+    if (active[k]) {
+    const uint32_t *env_rec = mix_lds + (size_t)(k * EN + e * N) * RS;
     const uint32_t *me = env_rec + (size_t)i * RS;
-    const float raw_i = __uint_as_float(me[W + 1]);
-    r = (1.0f - f.coop) * raw_i;                                       // uav.py:290
-    if (SMALL) {
-        const unsigned long long mask = (unsigned long long)me[0] | ((unsigned long long)me[1] << 32);
-        if (mask && !(mask & (mask - 1))) {
-            // ONE neighbour: its softmax weight is exp(s - s) / exp(s - s) = 1 whatever the score (uav.py:287-288), so the score
-            // is not read -- and where both UAVs of a pair are each other's only neighbour the rollout kernel never emitted
-            // it (step_kernel.hip, drop_isolated).  fmaf(1, raw_j, 0) / 1 = raw_j: the same bits as the general form below.
-            r = fmaf(f.coop, __uint_as_float(env_rec[(size_t)(__ffsll((long long)mask) - 1) * RS + 3]), r);
-        } else if (mask) {
-            auto slot_of = [&](int j) {                // where s_ij lives: emitted by the lower index
-                const int lo = j > i ? i : j, hi = j > i ? j : i;
-                const uint32_t *rl = env_rec + (size_t)lo * RS;
-                const unsigned long long ml = (unsigned long long)rl[0] | ((unsigned long long)rl[1] << 32);
-                const unsigned long long later = (lo + 1 < 64) ? (ml >> (lo + 1)) << (lo + 1) : 0ull;
-                return rl[2] + (unsigned)__popcll(later & ((1ull << hi) - 1ull));
-            };
-            float mx = -INFINITY;
-            for (unsigned long long m = mask; m; m &= m - 1) mx = fmaxf(mx, f.scores[slot_of(__ffsll((long long)m) - 1)]);
-            float den = 0.0f, num = 0.0f;
-            for (unsigned long long m = mask; m; m &= m - 1) {          // ascending j: scipy softmax, uav.py:287
-                const int j = __ffsll((long long)m) - 1;
-                const float ew = expf(f.scores[slot_of(j)] - mx);
-                den += ew;
-                num = fmaf(ew, __uint_as_float(env_rec[(size_t)j * RS + 3]), num);
+    const float *raw_of = rv + k * EN + e * N;
+    float rr = raw_of[i];                                              // no neighbours: already (1 - a) raw_i, clipped (uav.py:290)
+    if (WS) {
+        auto mask_of = [&](const uint32_t *rec) {
+            return WS == 1 ? (unsigned long long)rec[0] : ((unsigned long long)rec[0] | ((unsigned long long)rec[1] << 32));
+        };
+        const unsigned long long mask = mask_of(me);
+        if (mask) {
+            rr = (1.0f - f.coop) * rr;
+            if (!(mask & (mask - 1))) {
+                // ONE neighbour: its softmax weight is exp(s - s) / exp(s - s) = 1 whatever the score (uav.py:287-288), so the
+                // score is not read -- and where both UAVs of a pair are each other's only neighbour the rollout kernel never
+                // emitted it (step_kernel.hip, drop_isolated).  fmaf(1, raw_j, 0) / 1 = raw_j: the bits of the general form.
+                rr = fmaf(f.coop, raw_of[__ffsll((long long)mask) - 1], rr);
+            } else {
+                auto slot_of = [&](int j) {                // where s_ij lives: emitted by the lower index
+                    const int lo = j > i ? i : j, hi = j > i ? j : i;
+                    const uint32_t *rl = env_rec + (size_t)lo * RS;
+                    const unsigned long long ml = mask_of(rl);
+                    const unsigned long long later = (lo + 1 < 64) ? (ml >> (lo + 1)) << (lo + 1) : 0ull;
+                    return rl[W] + (unsigned)__popcll(later & ((1ull << hi) - 1ull));
+                };
+                float mx = -INFINITY;
+                for (unsigned long long m = mask; m; m &= m - 1) mx = fmaxf(mx, f.scores[slot_of(__ffsll((long long)m) - 1)]);
+                float den = 0.0f, num = 0.0f;
+                for (unsigned long long m = mask; m; m &= m - 1) {          // ascending j: scipy softmax, uav.py:287
+                    const int j = __ffsll((long long)m) - 1;
+                    const float ew = expf(f.scores[slot_of(j)] - mx);
+                    den += ew;
+                    num = fmaf(ew, raw_of[j], num);
+                }
+                rr = fmaf(f.coop, num / den, rr);                            // uav.py:288
             }
-            r = fmaf(f.coop, num / den, r);                              // uav.py:288
+            rr = fminf(fmaxf(rr, -1.0f), 1.0f);                              // environment.py:225
+            f.reward[gid[k]] = rr;
         }
     } else {
         auto bit = [&](const uint32_t *rec, int j) { return (rec[j >> 5] >> (j & 31)) & 1u; };
@@ -1077,7 +1113,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) pmi_mix_kernel(const MixParams 
             const int lo = j > i ? i : j, hi = j > i ? j : i;
             const uint32_t *rl = env_rec + (size_t)lo * RS;
             unsigned rank = 0;
-            for (int k = lo + 1; k < hi; ++k) rank += bit(rl, k);
+            for (int q = lo + 1; q < hi; ++q) rank += bit(rl, q);
             return rl[W] + rank;
         };
         float mx = -INFINITY;
@@ -1090,23 +1126,29 @@ __global__ void __launch_bounds__(kMaxWorkgroup) pmi_mix_kernel(const MixParams 
                 if (bit(me, j)) {
                     const float ew = expf(f.scores[slot_of(j)] - mx);
                     den += ew;
-                    num = fmaf(ew, __uint_as_float(env_rec[(size_t)j * RS + W + 1]), num);
+                    num = fmaf(ew, raw_of[j], num);
                 }
-            r = fmaf(f.coop, num / den, r);
+            rr = fmaf(f.coop, num / den, (1.0f - f.coop) * rr);
+            rr = fminf(fmaxf(rr, -1.0f), 1.0f);
+            f.reward[gid[k]] = rr;
         }
     }
-    r = fminf(fmaxf(r, -1.0f), 1.0f);                                // environment.py:225
-    f.reward[gid] = r;
+    r[k] = rr;
+    }
     }
     if (f.rsum) {      // mean over the instance's UAVs, fixed order (train.py:181: the episode return adds these up over t)
-        float *rl = reinterpret_cast<float *>(mix_lds + (size_t)f.E * N * RS);      // (its own region behind the staged records)
-        if (active) rl[tid] = r;
+        float *rl = rv + (size_t)kMixBatch * EN;      // (its own region behind the staged slots: neighbours may still be reading those)
+#pragma unroll
+        for (int k = 0; k < kMixBatch; ++k)
+            if (active[k]) rl[k * EN + tid] = r[k];
         __syncthreads();
-        if (active && i == 0) {
-            float sum = 0.0f;
-            for (int j = 0; j < N; ++j) sum += rl[e * N + j];
-            f.rsum[env0 + e] = sum * (1.0f / (float)N);
-        }
+#pragma unroll
+        for (int k = 0; k < kMixBatch; ++k)
+            if (active[k] && i == 0) {
+                float sum = 0.0f;
+                for (int j = 0; j < N; ++j) sum += rl[k * EN + e * N + j];
+                f.rsum[(blockIdx.x * kMixBatch + k) * f.E + e] = sum * (1.0f / (float)N);
+            }
     }
 }
 
@@ -1368,12 +1410,15 @@ hipError_t launch_pmi_finalize(const uavtrack_env *env, int steps, float *reward
     const int wgs = dflt;
     f.SB = steps * c.n_envs; f.N = c.n_uav; f.E = wgs / c.n_uav;
     f.coop = env->base.coop;
-    const unsigned groups = (unsigned)((f.SB + f.E - 1) / f.E);
-    const size_t lds = (size_t)f.E * f.N * (nbrec_words(c.n_uav) + 1) * 4;         // records + one float per lane (per-step mean)
-    if (c.n_uav <= 64)
-        hipLaunchKernelGGL(pmi_mix_kernel<true>, dim3(groups), dim3(wgs), lds, stream, f);
+    const int kMixBatch = mix_batch(c.n_uav <= 64 ? 1 : 0);
+    const unsigned groups = (unsigned)((f.SB + f.E * kMixBatch - 1) / (f.E * kMixBatch));
+    const size_t lds = (size_t)kMixBatch * f.E * f.N * (nbrec_words(c.n_uav) + 2) * 4;     // records + reward slots + one float per lane (per-step mean)
+    if (c.n_uav <= 32)
+        hipLaunchKernelGGL(pmi_mix_kernel<1>, dim3(groups), dim3(wgs), lds, stream, f);
+    else if (c.n_uav <= 64)
+        hipLaunchKernelGGL(pmi_mix_kernel<2>, dim3(groups), dim3(wgs), lds, stream, f);
     else
-        hipLaunchKernelGGL(pmi_mix_kernel<false>, dim3(groups), dim3(wgs), lds, stream, f);
+        hipLaunchKernelGGL(pmi_mix_kernel<0>, dim3(groups), dim3(wgs), lds, stream, f);
     return hipGetLastError();
 }
 

@@ -703,11 +703,19 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     unsigned pe_base = 0, pe_tg = 0;        // (thread 0) the reservation in flight; flat [t][b][i] of the pending step
     int pe_mine = 0, pe_slot = 0;
     unsigned long long pe_nball = 0, pe_later = 0;
-    float pe_raw = 0.0f;
+    auto pmi_reward_slot = [&](bool has_neighbours, float raw_i) {
+        return has_neighbours ? raw_i : fminf(fmaxf((1.0f - p.coop) * raw_i, -1.0f), 1.0f);
+    };
+    auto store_record = [&](unsigned tg, unsigned long long nball, unsigned first) {      // N <= 64 (internal.h, nbrec_words)
+        if (N <= 32) *reinterpret_cast<uint2 *>(p.nbrec + (size_t)tg * 2) = make_uint2((unsigned)nball, first);
+        else {
+            uint32_t *rec = p.nbrec + (size_t)tg * 3;
+            rec[0] = (unsigned)nball; rec[1] = (unsigned)(nball >> 32); rec[2] = first;
+        }
+    };
     auto commit_pairs = [&](unsigned base) {
         const unsigned first = base + (unsigned)pe_slot;
-        uint32_t *rec = p.nbrec + (size_t)pe_tg * (nbrec_mask_words(N) + 2);
-        *reinterpret_cast<uint4 *>(rec) = make_uint4((unsigned)pe_nball, (unsigned)(pe_nball >> 32), first, __float_as_uint(pe_raw));
+        store_record(pe_tg, pe_nball, first);
         if (pe_mine) {
             uint2 *dst = p.pairs + first;
             unsigned long long later = pe_later;
@@ -1024,6 +1032,11 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                 }
             }
             r = fminf(fmaxf(r, -1.0f), 1.0f);   // clip_and_normalize(reward, -1, 1), environment.py:225
+            // MAAC-R: the reward slot carries what the mix stage needs of this UAV -- its RAW reward while it has neighbours
+            // (they read it, and the mix overwrites it with the final value), its FINAL reward (1 - a) raw, clipped
+            // (uav.py:290, environment.py:225), when it has none: the mix then neither recomputes nor rewrites it.
+            // (unspecialised shapes: the neighbour set is only known in the emission block below, which stores it again)
+            if (MODE == UAVTRACK_REWARD_PMI) r = pmi_reward_slot(kMask ? (nbmask & ~(1ull << i)) != 0ull : true, raw);
 
             ++count;
             // the prefetched action is consumed HERE, ahead of this step's stores: vector-memory operations
@@ -1122,8 +1135,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             }
             real_pairs += total;
             if (active) {
-                uint32_t *rec = p.nbrec + (size_t)tg_off * (nbrec_mask_words(N) + 2);
-                *reinterpret_cast<uint4 *>(rec) = make_uint4((unsigned)nball, (unsigned)(nball >> 32), first, __float_as_uint(raw));
+                store_record(tg_off, nball, first);
                 uint2 *dst = p.pairs + first;
                 while (later) {                      // ascending j
                     const int j = __ffsll((long long)later) - 1;
@@ -1152,7 +1164,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             }
             __syncthreads();
             if (tid == 0) { pe_base = wg_cnt[0] ? atomicAdd(p.pair_count, wg_cnt[0]) : 0u; real_pairs += wg_cnt[0]; }
-            pe_mine = mine; pe_slot = slot; pe_nball = nball; pe_later = later; pe_tg = tg_off; pe_raw = raw;
+            pe_mine = mine; pe_slot = slot; pe_nball = nball; pe_later = later; pe_tg = tg_off;
         } else
         if (MODE == UAVTRACK_REWARD_PMI) {
             unsigned *wg_cnt = covw + 2 * E * CW;          // two extra words behind the coverage masks
@@ -1187,18 +1199,20 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             __syncthreads();
             if (active) {
                 const unsigned first = wg_cnt[1] + (unsigned)slot;
-                uint32_t *rec = p.nbrec + (size_t)tg_off * (W + 2);
+                bool any = nball != 0ull;
                 if (N <= 64) {
-                    *reinterpret_cast<uint4 *>(rec) = make_uint4((unsigned)nball, (unsigned)(nball >> 32), first, __float_as_uint(raw));
+                    store_record(tg_off, nball, first);
                 } else {
+                    uint32_t *rec = p.nbrec + (size_t)tg_off * (W + 1);
                     for (int w = 0; w < W; ++w) {
                         unsigned bits = 0;
                         for (int j = 32 * w; j < min(N, 32 * w + 32); ++j) bits |= (is_neighbour(j) ? 1u : 0u) << (j - 32 * w);
                         rec[w] = bits;
+                        any = any || bits != 0u;
                     }
                     rec[W] = first;
-                    rec[W + 1] = __float_as_uint(raw);
                 }
+                *at(p.reward + row, g32 * 4u) = pmi_reward_slot(any, raw);      // (the reward slot's MAAC-R content, see P4)
                 if (mine) {
                     uint2 *dst = p.pairs + first;
                     if (N <= 64) {
