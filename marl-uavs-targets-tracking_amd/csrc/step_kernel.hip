@@ -101,6 +101,25 @@ __device__ __forceinline__ v2f pk_le_mask(v2f d2, v2f neg_scale, float c)
 // rounded, then one fma.  Scalar and packed forms give identical bits.
 __device__ __forceinline__ float dist2(float dx, float dy) { return fmaf(dy, dy, dx * dx); }
 
+// Inclusive prefix sum of a small integer over the 64 lanes of a wavefront, in lane order, on the DPP paths: Kogge-Stone inside
+// each row of 16 (shifts that leave the row bring in 0), then lane 15 of rows 0 and 2 into rows 1 and 3, then lane 31 into
+// rows 2 and 3.  Every lane must be active (inactive lanes would contribute whatever their register holds).
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp_add_i(int v)
+{
+    return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ int wave_inclusive_sum(int v)
+{
+    v = dpp_add_i<0x111>(v);           // row_shr:1
+    v = dpp_add_i<0x112>(v);           // row_shr:2
+    v = dpp_add_i<0x114>(v);           // row_shr:4
+    v = dpp_add_i<0x118>(v);           // row_shr:8
+    v = dpp_add_i<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v = dpp_add_i<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // Workgroups are dealt round-robin over the 8 XCDs; give consecutive environment
 // groups to one XCD so neighbouring output spans land in the same L2 (speed only).
 __device__ __forceinline__ int xcd_group(int bid, int nwg)
@@ -1084,21 +1103,18 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         //      (the input is la_i * la_j), so unordered pairs halve the work.
         if (kPoolEmit) {
             unsigned *wg_cnt = covw + 2 * E * CW;          // (a wavefront's LDS operations execute in program order)
-            if (tid == 0) wg_cnt[0] = 0;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            int mine = 0, slot = 0;
+            int mine = 0;
             unsigned long long nball = 0, later = 0;        // all neighbours / neighbours j > i
             if (active) {
                 nball = nbmask & ~(1ull << i);
                 later = drop_isolated(nball, (i + 1 < 64) ? (nball >> (i + 1)) << (i + 1) : 0ull);
                 mine = __popcll(later);
-                if (mine) slot = (int)atomicAdd(&wg_cnt[0], (unsigned)mine);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const unsigned total = (unsigned)__builtin_amdgcn_readfirstlane((int)wg_cnt[0]);
+            // every lane's run of slots: an inclusive prefix sum over the wavefront on the cross-lane (DPP) paths -- no trip to the
+            // LDS (an LDS atomic per lane and the read-back of the total were three dependent round trips per step)
+            const int incl = wave_inclusive_sum(mine);
+            const int slot = incl - mine;
+            const unsigned total = (unsigned)__builtin_amdgcn_readlane(incl, 63);
             unsigned first = pool_base + (unsigned)slot;
             if (total > pool_left) {
                 // This step does not fit.  UAVs whose run of slots still fits keep the old block (they are a prefix in slot
