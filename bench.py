@@ -373,12 +373,16 @@ def device_warmup(uavtrack, args, B, device, warm_ms=DEVICE_WARM_MS):
     starts at the clocks of a GPU under load, not at those of one waking up (see DEVICE_WARM_MS).  Returns a description."""
     import torch
     env = make_env(uavtrack, args, B, device)
-    T = 50
+    # (the launch length of the timed rollouts: every rollout launch of a default run is then a 200-step launch, and the
+    #  rocprofv3 --kernel-trace average of the same command is the average of one launch shape, like the roofline leg's)
+    T = max(1, min(getattr(args, "rollout", ROOFLINE_T), ROOFLINE_T))
     g = torch.Generator(device=device).manual_seed(1)
     actions = torch.randint(0, env.cfg.na_total, (T, B, args.n_uav), dtype=torch.int32, device=device, generator=g)
     obs = env.reset(seed=1)
 
     def one(out):
+        env.reset(seed=1)       # (every launch an episode from the reset state, like the measured ones: under MAAC-R the
+                                #  number of neighbour pairs -- the scorer's work -- depends on where the swarm is)
         if args.policy == "actor":
             return env.run_actor(T, obs, seed=1, out=out)
         if args.policy == "greedy":

@@ -55,6 +55,19 @@ class EnvConfig:
             return RewardMode(self.reward_mode)
         return RewardMode.RAW if self.cooperative == 0 else RewardMode.MEAN
 
+    def clip_can_overstep(self) -> dict:
+        """Which of the reference's four `clip_and_normalize` calls (environment.py:206-225) can meet a value outside its
+        range with these constants -- where the reference prints "overstep in clip." (data_util.py:44-47) and the kernels
+        clamp silently.  tracking: sum over m_targets of at most 2 each against the ceiling 2 * norm_m_targets; duplicate:
+        n_uav - 1 terms of at least -e/2 each against the floor -e/2 * norm_n_uav; boundary: never (the raw term is in
+        [-1/2, 0] by construction); reward: a weighted sum of terms in [0, 1], [-1, 0], [-1, 0] against [-1, 1]."""
+        nn = self.n_uav if self.norm_n_uav is None else self.norm_n_uav
+        nm = max(1, self.m_targets if self.norm_m_targets is None else self.norm_m_targets)
+        hi = max(self.alpha, 0.0) + max(-self.beta, 0.0) + max(-self.gamma, 0.0)
+        lo = min(self.alpha, 0.0) - max(self.beta, 0.0) - max(self.gamma, 0.0)
+        return {"tracking": self.m_targets > nm, "duplicate": self.n_uav - 1 > nn, "boundary": False,
+                "reward": hi > 1.0 or lo < -1.0}
+
     @classmethod
     def from_reference_dict(cls, config: Mapping[str, Any], n_envs: int = 1, **over) -> "EnvConfig":
         """Accepts the dict shape args_util.get_config produces (keys read at

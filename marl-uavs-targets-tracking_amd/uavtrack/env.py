@@ -415,6 +415,16 @@ class BatchedUavEnv:
             res["targets"] = tp
         return res
 
+    @staticmethod
+    def clip_saturation(terms: torch.Tensor, reward: torch.Tensor) -> Dict[str, int]:
+        """Diagnostic counterpart of the reference's "overstep in clip." print (data_util.py:44-47): how many values of a
+        rollout's outputs sit ON a clip bound -- terms [..., 3, B, N] (tracking at 1, duplicate at -1) and reward [..., B, N]
+        (at +-1).  A raw value beyond the bound ends there (the kernels clamp like `np.clip`), so a non-zero count where
+        `EnvConfig.clip_can_overstep()` says it can happen is the reference's message; exactly on the bound is counted too."""
+        tt, dup = terms.select(-3, 0), terms.select(-3, 2)
+        return {"tracking": int((tt >= 1.0).sum()), "duplicate": int((dup <= -1.0).sum()),
+                "reward": int((reward.abs() >= 1.0).sum())}
+
     def set_profiling(self, on: bool) -> None:
         """HIP event pairs around every kernel launch of the stepping calls (uavtrack_set_profiling); read with profile()."""
         _lib.check(self._lib.uavtrack_set_profiling(self._h, C.c_int32(1 if on else 0)), "uavtrack_set_profiling")

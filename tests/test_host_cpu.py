@@ -531,3 +531,28 @@ def test_t3_block_scaled_f16_split_error_model():
             e = np.abs(got - ref)
             assert (e <= 1e-5 * np.maximum(mag, 1e-30)).all(), (name, slack, (e / np.maximum(mag, 1e-30)).max())
             assert e.max() <= 2.0 * ec.max() + 1e-6 * mag.max(), (name, slack, e.max(), ec.max())
+
+
+def test_clip_overstep_diagnostics():
+    """The reference prints "overstep in clip." when a raw term leaves its range (data_util.py:44-47); the kernels clamp.
+    `EnvConfig.clip_can_overstep` says from the constants alone which of the four clips can trigger (the reference's own
+    configurations: none), `BatchedUavEnv.clip_saturation` counts the outputs that sit on a bound -- checked here on the
+    oracle's outputs for a configuration whose tracking ceiling is below what ten targets can add up to."""
+    import torch
+    import uavtrack
+    from oracle import OracleConfig, OracleEnv
+    assert uavtrack.EnvConfig(n_uav=20, m_targets=10).clip_can_overstep() == {"tracking": False, "duplicate": False, "boundary": False, "reward": False}
+    c = uavtrack.EnvConfig(n_uav=20, m_targets=10, norm_m_targets=1, norm_n_uav=5, alpha=1.5)
+    assert c.clip_can_overstep() == {"tracking": True, "duplicate": True, "boundary": False, "reward": True}
+    assert uavtrack.EnvConfig(n_uav=6, m_targets=3, norm_n_uav=5).clip_can_overstep()["duplicate"] is False      # 5 terms against 5
+    B, N, M = 16, 20, 10
+    orc = OracleEnv(OracleConfig(n_envs=B, n_uav=N, m_targets=M, norm_m_targets=1, x_max=300.0, y_max=300.0), n_threads=2)
+    orc.reset_philox(3)
+    rng = np.random.RandomState(0)
+    terms, rewards = [], []
+    for _ in range(5):
+        out = orc.step(rng.randint(0, 12, size=(B, N)).astype(np.int32))
+        terms.append(out["terms"]); rewards.append(out["reward"])
+    terms, rewards = np.stack(terms), np.stack(rewards)
+    got = uavtrack.BatchedUavEnv.clip_saturation(torch.from_numpy(terms), torch.from_numpy(rewards))
+    assert got["tracking"] == int((terms[:, 0] >= 1.0).sum()) > 0 and got["duplicate"] == 0 and got["reward"] == 0
