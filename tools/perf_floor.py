@@ -10,9 +10,10 @@ import sys
 
 FLOORS = {   # cfg substring -> (key, floor)
     "4096x20x10 2D raw (timed region)": ("frac", 0.43),
-    "configs[2] MAAC-R, PMI hidden 128": ("G", 9.0),
-    "configs[2] MAAC-R, PMI hidden 64": ("G", 13.0),
-    "configs[3] 3-D": ("frac", 0.30),
+    "configs[2] MAAC-R, PMI hidden 128": ("G", 10.7),
+    "configs[2] MAAC-R, PMI hidden 64": ("G", 14.3),
+    "configs[2] MAAC-R dense": ("G", 5.6),
+    "configs[3] 3-D": ("frac", 0.31),
     "chip-filling": ("frac", 0.55),
 }
 
@@ -29,6 +30,11 @@ def main(path):
     cl = [c for c in line["configs"] if c["cfg"].startswith("closed loop")]
     if cl:
         print("closed loop:", {k: v for k, v in cl[0].items() if k != "cfg"})
+        for key, floor in (("actor_fused", 11.0), ("actor_chunks", 8.3), ("actor_fused_maac_r", 6.5), ("greedy_fused", 12.8)):
+            if key in cl[0]:
+                ok = cl[0][key] >= floor
+                bad += not ok
+                print(f"{'ok  ' if ok else 'MISS'} closed loop {key:<56s} G = {cl[0][key]:<8g} floor {floor}")
     return 1 if bad else 0
 
 
