@@ -361,6 +361,8 @@ def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, en
             T0 = max(set(timed_plan), key=timed_plan.count)
             roll = dict(obs=out[T0]["obs"], reward=out[T0]["reward"], actions=actions[:T0] if "actions" not in out[T0] else out[T0]["actions"])
             smp = uavtrack.sample_local_transitions(first_obs, roll, min(k_tr, T0 * B * args.n_uav), env_offset=env_offset, n_envs_total=total_envs, generator=tgen)
+            gather_info["transitions_sample_ms"] = timed(lambda: uavtrack.sample_local_transitions(
+                first_obs, roll, min(k_tr, T0 * B * args.n_uav), env_offset=env_offset, n_envs_total=total_envs, generator=tgen))
             gather_info["transitions_ms"] = timed(lambda: uavtrack.gather_transitions(smp))
             gather_info["transitions_bytes_per_rank"] = smp["actions"].shape[0] * 28 * 4
             gather_info["transitions_per_rank"] = int(smp["actions"].shape[0])

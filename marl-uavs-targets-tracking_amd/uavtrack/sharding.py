@@ -103,7 +103,15 @@ def sample_local_transitions(obs_in, out, k: int, env_offset: int = 0, n_envs_to
     if n_envs_total is None:
         n_envs_total = B
     dev = rew.device
-    pick = torch.randperm(n, device=dev, generator=generator)[:k]
+    if 16 * k <= n:
+        # k << n (4096 of 16.4 M at the reference shape): a permutation of all n would cost more than the rollout.  The
+        # distinct values among m uniform draws are a uniform random subset of their size; a uniform k-subset of that set
+        # is a uniform k-subset of the rollout, and the permutation that picks it also randomises the order.
+        cand = torch.unique(torch.randint(0, n, (k + k // 4 + 64,), device=dev, generator=generator))
+        pick = (cand[torch.randperm(cand.numel(), device=dev, generator=generator)[:k]] if cand.numel() >= k
+                else torch.randperm(n, device=dev, generator=generator)[:k])
+    else:
+        pick = torch.randperm(n, device=dev, generator=generator)[:k]
     t, rem = pick // (B * N), pick % (B * N)
     b, i = rem // N, rem % N
     prev = obs[(t - 1).clamp(min=0), b, i]
