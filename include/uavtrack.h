@@ -266,7 +266,9 @@ int uavtrack_run_actor(uavtrack_env *env, int32_t T, uint64_t seed, int32_t mode
 int uavtrack_set_target_trace(uavtrack_env *env, float *tpos, int32_t capacity_steps);
 
 /* MAAC-R accounting for reports: out[0] = neighbour pairs the stepping entry points have handed to the PMI network
- * since the handle was created (each unordered pair once per step).  Synchronises `stream`. */
+ * since the handle was created (each unordered pair once per step).  A pair of UAVs that are each other's ONLY
+ * neighbour is not among them: the softmax over a single neighbour is 1 whatever its score (uav.py:287-288), so such a
+ * pair is never scored.  Synchronises `stream`. */
 int uavtrack_pmi_pairs_scored(uavtrack_env *env, uint64_t *out, void *stream);
 
 /* Measurement hook (bench.py's roofline legs): with profiling on, every kernel launch of the stepping entry points is
