@@ -399,7 +399,7 @@ def test_lds_need_follows_reward_mode(uavtrack):
     raw.close(); mean.close()
 
 
-@pytest.mark.parametrize("n,m,shape", [(20, 10, "specialised"), (7, 4, "generic")])
+@pytest.mark.parametrize("n,m,shape", [(20, 10, "specialised"), (7, 4, "generic"), (50, 25, "specialised"), (40, 6, "generic")])
 def test_maac_r_isolated_pairs_are_not_scored(uavtrack, pmi_state_dict, n, m, shape):
     """uav.py:287-288: the softmax over ONE neighbour is 1 whatever its score, so two UAVs that are each other's only
     neighbour need no score; the rollout kernel does not emit such a pair and the mix kernel does not read one.  Hand-placed
