@@ -231,13 +231,14 @@ void fold_constants(const uavtrack_config &c, StepParams &p, float *climb_c, flo
         // (at most e * 2^b) must stay below 2^22, and n_uav of them below 2^32
         const int b = kSymBits;
         p.sym_k0 = (float)(log2e + b);
-        p.sym_inv = std::ldexp(1.0f, -b);
     }
     p.tt_ceil = (float)(2.0 * c.norm_m_targets);
     p.inv_tt_ceil = (float)(1.0 / (2.0 * c.norm_m_targets));
-    const double dup_floor = -M_E / 2.0 * c.norm_n_uav;
-    p.dup_floor = (float)dup_floor;
-    p.inv_dup = (float)(1.0 / -dup_floor);
+    // duplicate punishment (uav.py:214-229: -0.5 sum g) clipped to [-e/2 N, 0] and normalised to [-1, 0] (environment.py:210,
+    // data_util.py choice -1: (v - floor) / (0 - floor) - 1 = v / |floor|), as ONE multiply and a clamp: clamp(k sum g, -1, 0)
+    const double dup_k = -0.5 / (M_E / 2.0 * c.norm_n_uav);
+    p.dup_k = (float)dup_k;
+    p.sym_dup_k = (float)std::ldexp(dup_k, -kSymBits);
     p.alpha = (float)c.alpha; p.beta = (float)c.beta; p.gamma = (float)c.gamma;
     p.coop = (float)c.cooperative;
     for (int k = 0; k < UAVTRACK_MAX_CLIMB; ++k) {

@@ -97,9 +97,10 @@ struct StepParams {
     float inv_na;                // 1 / na: the climb index of a 3-D action is floor((a + 0.5) / na)
     float act_bias, inv_act_bias;   // step_kernel.hip act_bias_shape(): K, a power of two above n_uav * na * nc, and 1 / K
     float exp_k0, exp_k1;        // exp((2dp-d)/(2dp)) = exp2(k0 - k1*d)   (uav.py:226)
-    float sym_k0, sym_inv;       // step_kernel.hip sym_dup: k0 + b and 2^-b, b = kSymBits the fixed-point bits of the shared duplicate term
+    float sym_k0;                // step_kernel.hip sym_dup: k0 + b, b = kSymBits the fixed-point bits of the shared duplicate term
     float tt_ceil, inv_tt_ceil;  // 2*m_targets                   (environment.py:208)
-    float dup_floor, inv_dup;    // -e/2*n_uav and 1/(e/2*n_uav)  (environment.py:210)
+    float dup_k, sym_dup_k;      // the duplicate term's clip and normalisation folded (environment.py:210,217): dup = clamp(k * sum g, -1, 0)
+                                 // with k = -0.5 / (e/2 * n_uav) for a float sum of g, times 2^-kSymBits for sym_dup's fixed-point sum
     float alpha, beta, gamma, coop;
 };
 

@@ -395,26 +395,28 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
         const unsigned w = (unsigned)nbf.y | ((unsigned)nbf.x << 1);
         nbmask = (unsigned long long)(__brev(w) >> (32 - 2 * NP));
     }
-    // ---- self terms.  Post-move table: distance 0, exp2(k0).  Sequential view: odd i shares its pair
-    //      with j = i - 1 < i, so it saw its own post-move pose (d = 0); even i saw its own pre-move pose.
+    // ---- self terms.  Post-move table: distance 0, exp2(k0).  Sequential view: odd i shares its pair with j = i - 1 < i,
+    //      so it saw its own post-move pose: d = 0, always in range, every difference to itself 0 -- for those lanes
+    //      sum_j m (c_j - c_i) over the OTHER peers is just (sum over all m c) - c_i * (count over all), no correction term.
+    //      Even i saw its own pre-move pose, in range or not (mse): the same expression with the count over all, then
+    //      - mse * (c_old - c_i), and the pre-move offset taken out of the position sums.
     const bool odd = i & 1;
-    const float dxs = odd ? 0.0f : xo - xi, dys = odd ? 0.0f : yo - yi;
+    const float dxs = xo - xi, dys = yo - yi;
     float d2s = dist2(dxs, dys);
-    if (Z3) { const float dzs = odd ? 0.0f : zo - zi; d2s = fmaf(dzs, dzs, d2s); }
-    const float ms = (d2s <= p.dc2) ? 1.0f : 0.0f;
+    if (Z3) { const float dzs = zo - zi; d2s = fmaf(dzs, dzs, d2s); }
+    const float mse = (!odd && d2s <= p.dc2) ? 1.0f : 0.0f;
     a.dup = dup.x + dup.y - fast_exp2(p.exp_k0);
     float cnt_all = cnt.x + cnt.y, sa_all = sa.x + sa.y;
     if (kActBias) {   // the table's action slot holds a + K: sum m (a + K) = K * count + sum m a, both exact small integers
         cnt_all = floorf(sa_all * p.inv_act_bias);
         sa_all = fmaf(-p.act_bias, cnt_all, sa_all);
     }
-    a.cntU = cnt_all - ms; a.iwU = a.cntU;
-    a.sxU = sx.x + sx.y - ms * dxs;
-    a.syU = sy.x + sy.y - ms * dys;
-    // sum_j m (c_j - c_i) = sum_j m c_j - c_i cnt
-    a.scU = fmaf(-ci, a.cntU, sc.x + sc.y - ms * (odd ? ci : co));
-    a.ssU = fmaf(-si, a.cntU, ss.x + ss.y - ms * (odd ? si : so));
-    a.saU = fmaf(-ai, a.cntU, sa_all - ms * (odd ? ai : ao));
+    a.cntU = cnt_all - (odd ? 1.0f : mse); a.iwU = a.cntU;
+    a.sxU = fmaf(-mse, dxs, sx.x + sx.y);
+    a.syU = fmaf(-mse, dys, sy.x + sy.y);
+    a.scU = fmaf(-mse, co - ci, fmaf(-ci, cnt_all, sc.x + sc.y));
+    a.ssU = fmaf(-mse, so - si, fmaf(-si, cnt_all, ss.x + ss.y));
+    a.saU = fmaf(-mse, ao - ai, fmaf(-ai, cnt_all, sa_all));
 }
 
 // The duplicate-tracking term (uav.py:214-229) is symmetric on the post-move poses: g(d_ij) enters UAV i's sum and UAV j's.
@@ -567,10 +569,10 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     StepParams p = p_in;
     if (kVConst) {
 #define UAVTRACK_V(f) p.f = vreg(p_in.f)
-        UAVTRACK_V(inv_dp); UAVTRACK_V(inv_dc); UAVTRACK_V(dp2); UAVTRACK_V(dc2); UAVTRACK_V(dup_floor); UAVTRACK_V(inv_dup);
+        UAVTRACK_V(inv_dp); UAVTRACK_V(inv_dc); UAVTRACK_V(dp2); UAVTRACK_V(dc2); UAVTRACK_V(dup_k); UAVTRACK_V(sym_dup_k);
         UAVTRACK_V(vratio); UAVTRACK_V(inv_na_total); UAVTRACK_V(exp_k0); UAVTRACK_V(exp_k1); UAVTRACK_V(x_max); UAVTRACK_V(y_max);
         UAVTRACK_V(tt_ceil); UAVTRACK_V(inv_tt_ceil); UAVTRACK_V(alpha); UAVTRACK_V(beta); UAVTRACK_V(gamma);
-        UAVTRACK_V(sym_k0); UAVTRACK_V(sym_inv); UAVTRACK_V(act_bias); UAVTRACK_V(inv_act_bias);
+        UAVTRACK_V(sym_k0); UAVTRACK_V(act_bias); UAVTRACK_V(inv_act_bias);
         UAVTRACK_V(le_neg_scale); UAVTRACK_V(le_dp2); UAVTRACK_V(lt_dp2); UAVTRACK_V(le_dc2); UAVTRACK_V(le_two_dp2);
         UAVTRACK_V(dtv_u); UAVTRACK_V(dtv_t); UAVTRACK_V(turn_unit); UAVTRACK_V(inv_na); UAVTRACK_V(two_dp2); UAVTRACK_V(dp); UAVTRACK_V(coop);
 #undef UAVTRACK_V
@@ -960,18 +962,21 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             }
 
             // ---- P3: local state (uav.py:156-190)
-            {   // empty list -> -1 (uav.py:174,186): computed unconditionally, selected afterwards (0 * rcp(0) never survives)
-                const float rcU = fast_rcp(acc.cntU), rcT = fast_rcp(acc.cntT);
+            {   // empty list -> -1 (uav.py:174,186), branch-free and with two selects per list instead of one per entry: the
+                // reciprocal of an empty list's count becomes 0 and the addend -1, so every entry is one FMA
+                // (sum * scale) * rc + base -- the same products, in the same order, as the selected form
                 const bool anyU = acc.cntU > 0.0f, anyT = acc.cntT > 0.0f;
-                o[0] = anyU ? acc.sxU * p.inv_dc * rcU : -1.0f;
-                o[1] = anyU ? acc.syU * p.inv_dc * rcU : -1.0f;
-                o[2] = anyU ? acc.scU * rcU : -1.0f;
-                o[3] = anyU ? acc.ssU * rcU : -1.0f;
-                o[4] = anyU ? acc.saU * p.inv_na_total * rcU : -1.0f;
-                o[5] = anyT ? acc.sxT * p.inv_dp * rcT : -1.0f;
-                o[6] = anyT ? acc.syT * p.inv_dp * rcT : -1.0f;
-                o[7] = anyT ? acc.scT * rcT : -1.0f;
-                o[8] = anyT ? acc.ssT * rcT : -1.0f;
+                const float rcU = anyU ? fast_rcp(acc.cntU) : 0.0f, rcT = anyT ? fast_rcp(acc.cntT) : 0.0f;
+                const float baseU = anyU ? 0.0f : -1.0f, baseT = anyT ? 0.0f : -1.0f;
+                o[0] = fmaf(acc.sxU * p.inv_dc, rcU, baseU);
+                o[1] = fmaf(acc.syU * p.inv_dc, rcU, baseU);
+                o[2] = fmaf(acc.scU, rcU, baseU);
+                o[3] = fmaf(acc.ssU, rcU, baseU);
+                o[4] = fmaf(acc.saU * p.inv_na_total, rcU, baseU);
+                o[5] = fmaf(acc.sxT * p.inv_dp, rcT, baseT);
+                o[6] = fmaf(acc.syT * p.inv_dp, rcT, baseT);
+                o[7] = fmaf(acc.scT, rcT, baseT);
+                o[8] = fmaf(acc.ssT, rcT, baseT);
             }
             o[9] = x * p.inv_dc;
             o[10] = y * p.inv_dc;
@@ -984,8 +989,8 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             //   d < 0: -0.5 -> -1;  0 <= d < dp: -0.5 (dp - d) / dp -> d / dp - 1;  d >= dp: 0 -> 0   ==  clamp(d / dp, 0, 1) - 1
             bp = __builtin_amdgcn_fmed3f(d_bdr * p.inv_dp, 0.0f, 1.0f) - 1.0f;
             tt = __builtin_amdgcn_fmed3f(acc.trk, 0.0f, p.tt_ceil) * p.inv_tt_ceil;
-            if (!kSym) dupn = (__builtin_amdgcn_fmed3f(acc.dup * -0.5f, p.dup_floor, 0.0f) - p.dup_floor) * p.inv_dup - 1.0f;
-            if (!kSym) raw = p.alpha * tt + p.beta * bp + p.gamma * dupn;      // (kSym: behind the barrier, once the partners' halves are in)
+            if (!kSym) dupn = __builtin_amdgcn_fmed3f(acc.dup * p.dup_k, -1.0f, 0.0f);
+            if (!kSym) raw = fmaf(p.gamma, dupn, fmaf(p.beta, bp, p.alpha * tt));      // (kSym: behind the barrier, once the partners' halves are in)
             if (MODE == UAVTRACK_REWARD_MEAN) rawl[e * (N + 1) + i] = raw;
             // MAAC-R: the size of this UAV's neighbour set, for its neighbours to see behind the barrier (isolated pairs, below)
             if (MODE == UAVTRACK_REWARD_PMI && kMask) reinterpret_cast<int *>(rawl)[e * (N + 1) + i] = __popcll(nbmask & ~(1ull << i));
@@ -1011,9 +1016,9 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             if (kSym) {      // duplicate term: own half + what the partners added to this UAV's two accumulator entries
                 const unsigned *dq = reinterpret_cast<const unsigned *>(symbase + e * symstride + (Z3 ? 3 : 2) * symlen);
                 // (every UAV's three sums hold N - 1 terms between them: its own half and one from each partner)
-                const float dsum = (float)(sym_own + dq[i] + dq[N + i] - (unsigned)(N - 1) * 0x4B400000u) * p.sym_inv;
-                dupn = (__builtin_amdgcn_fmed3f(dsum * -0.5f, p.dup_floor, 0.0f) - p.dup_floor) * p.inv_dup - 1.0f;
-                raw = p.alpha * tt + p.beta * bp + p.gamma * dupn;
+                const float dsum = (float)(sym_own + dq[i] + dq[N + i] - (unsigned)(N - 1) * 0x4B400000u);      // sum g * 2^kSymBits
+                dupn = __builtin_amdgcn_fmed3f(dsum * p.sym_dup_k, -1.0f, 0.0f);
+                raw = fmaf(p.gamma, dupn, fmaf(p.beta, bp, p.alpha * tt));
             }
             float r = raw;
             if (MODE == UAVTRACK_REWARD_MEAN) {
