@@ -137,14 +137,21 @@ __device__ __forceinline__ float wrap_heading(float h)
     return fmaf(-rintf(h * (1.0f / kTwoPi)), kTwoPi, h);
 }
 
-// sin/cos for |h| <= pi (headings are kept wrapped) on the hardware's own v_sin_f32 / v_cos_f32 (argument in revolutions):
-// measured on gfx950 over [-pi, pi], the h / (2 pi) product included: |err| <= 2.7e-7 for both -- what the 22-instruction
-// quadrant reduction + minimax polynomials gave that these three instructions replace.
+// sin/cos for |h| <= pi (headings are kept wrapped) on the hardware's own v_sin_f32 / v_cos_f32 (argument in revolutions).
+// Measured on gfx950 over [-pi, pi]: the instructions themselves are good to 1.25e-7; the rounding of t = h / (2 pi) adds up
+// to 1.9e-7 rad at |h| = pi, so that error -- exact from one FMA, plus the low part of 1 / (2 pi) -- goes back in as a
+// first-order correction (sin += d cos, cos -= d sin): |err| <= 1.4e-7 for both, what the 22-instruction quadrant reduction
+// + minimax polynomials gave that these eight instructions replace.  (It matters next to the origin, where the uav.py:165
+// weights multiply an observation row by up to 1e5.)
 __device__ __forceinline__ void sincos_wrapped(float h, float *s, float *c)
 {
-    const float t = h * (1.0f / kTwoPi);
-    *s = __builtin_amdgcn_sinf(t);
-    *c = __builtin_amdgcn_cosf(t);
+    constexpr float kInvHi = 0.15915494309189535f;                                      // fl32(1 / (2 pi))
+    constexpr float kInvLo = (float)(0.15915494309189533576888 - (double)kInvHi);      // 1 / (2 pi) - kInvHi
+    const float t = h * kInvHi;
+    const float s0 = __builtin_amdgcn_sinf(t), c0 = __builtin_amdgcn_cosf(t);
+    const float d = fmaf(h, kInvLo, fmaf(h, kInvHi, -t)) * kTwoPi;                      // 2 pi * (h / (2 pi) - t)
+    *s = fmaf(d, c0, s0);
+    *c = fmaf(-d, s0, c0);
 }
 
 // (ocml's sincosf, with its large-argument path, only for injected state whose heading is out of range)

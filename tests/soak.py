@@ -36,12 +36,23 @@ def run(B, N, M, coop, box, steps, seed, dim=2):
             cen["covered"] += int(dc.sum()); cen["obs"] += int(do.sum()); cen["reward"] += int(dr.sum()); cen["any"] += int((dc | do | dr).sum())
         if not ok.any():
             continue
-        # near the origin the uav.py:165 weight 1/min(d,1) makes observation entries O(10..1000): mixed abs/rel
-        worst["obs"] = max(worst["obs"], float((np.abs(o - ref["obs"]) / (1.0 + np.abs(ref["obs"])))[ok].max()))
+        # near the origin the uav.py:165 weight 1/min(d,1) makes observation entries O(10..1000): mixed abs/rel, and an
+        # environment that holds such a UAV (post-move pose within 2.5 m of the origin: the kernel's own test for the weighted
+        # path) is held to the documented near-origin bound 2e-4 (weights up to 1e5 multiply fp32-level errors
+        # of poses and of sin / cos), every other one to 1e-5
+        st2 = {k: v.cpu().numpy() for k, v in env.get_state().items()}
+        near = ((np.abs(st2["ux"]) < 2.5) & (np.abs(st2["uy"]) < 2.5)).any(1)
+        eo = (np.abs(o - ref["obs"]) / (1.0 + np.abs(ref["obs"]))).reshape(B, -1).max(1)
+        if (ok & near).any():
+            worst["obs_near_origin"] = max(worst.get("obs_near_origin", 0.0), float(eo[ok & near].max()))
+            assert worst["obs_near_origin"] < 2e-4
+        ok_far = ok & ~near
+        if ok_far.any():
+            worst["obs"] = max(worst["obs"], float(eo[ok_far].max()))
         worst["rew"] = max(worst["rew"], float(np.abs(r - ref["reward"])[ok].max()))
         worst["terms"] = max(worst["terms"], float(np.abs(tm - ref["terms"])[:, ok].max()))
         bad_cov += int((cv != ref["covered"])[ok].sum())
-    print(f"B{B} N{N} M{M} coop{coop} box{box} dim{dim} steps{steps}: max|obs|={worst['obs']:.2e} max|rew|={worst['rew']:.2e} "
+    print(f"B{B} N{N} M{M} coop{coop} box{box} dim{dim} steps{steps}: max|obs|={worst['obs']:.2e} (near origin {worst.get('obs_near_origin', 0.0):.2e}) max|rew|={worst['rew']:.2e} "
           f"max|terms|={worst['terms']:.2e} covered mismatches={bad_cov} knife-edge envs skipped={skipped}/{total}; of those "
           f"really different: covered {cen['covered']}, obs {cen['obs']}, reward {cen['reward']}, any {cen['any']}", flush=True)
     CENSUS.append((skipped, total, cen["covered"], cen["obs"], cen["reward"], cen["any"]))
