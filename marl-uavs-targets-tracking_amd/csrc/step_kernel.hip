@@ -664,6 +664,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     // advances uniform base pointers (SGPRs) and each lane adds one 32-bit offset (validate() bounds
     // B * N * 48 below 4 GiB) -- `global_store ... v_off, s[base]` instead of 64-bit vector address math.
     const unsigned g32 = (unsigned)g;
+    unsigned lane_off4 = g32 * 4u, lane_off48 = g32 * (unsigned)(UAVTRACK_OBS_DIM * 4);     // byte offsets of this lane in a [b][i] row of floats / of observations
     size_t row = 0;              // t * B * N: start of this step's [b][i] row in the per-step arrays (uniform)
     size_t rowb = 0;             // t * B
     int act_next = 0;
@@ -1080,18 +1081,23 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             }
             er += r; ett += tt; ebp += bp; edup += dupn;
 
+            // (the per-lane byte offsets pass through an empty asm every step: left loop-invariant, the compiler adds it to each
+            //  output's base ONCE, outside the loop, and then advances 64-bit vector addresses by the uniform row stride with two
+            //  v_mad_u64_u32 and a v_lshl_add_u64 per array and step -- this way the uniform row base stays in scalar registers
+            //  and the stores take the `saddr + 32-bit voffset` form)
+            asm volatile("" : "+v"(lane_off4), "+v"(lane_off48));
             if (p.obs) {
-                float4 *op = at(reinterpret_cast<float4 *>(p.obs + row * UAVTRACK_OBS_DIM), g32 * (unsigned)(UAVTRACK_OBS_DIM * 4));
+                float4 *op = at(reinterpret_cast<float4 *>(p.obs + row * UAVTRACK_OBS_DIM), lane_off48);
                 op[0] = make_float4(o[0], o[1], o[2], o[3]);
                 op[1] = make_float4(o[4], o[5], o[6], o[7]);
                 op[2] = make_float4(o[8], o[9], o[10], o[11]);
             }
-            if (p.reward) *at(p.reward + row, g32 * 4u) = r;
+            if (p.reward) *at(p.reward + row, lane_off4) = r;
             if (p.terms) {                                    // [t][3][b][i]
                 float *tp = p.terms + 3 * row;
-                *at(tp, g32 * 4u) = tt;
-                *at(tp + BN, g32 * 4u) = bp;
-                *at(tp + 2 * BN, g32 * 4u) = dupn;
+                *at(tp, lane_off4) = tt;
+                *at(tp + BN, lane_off4) = bp;
+                *at(tp + 2 * BN, lane_off4) = dupn;
             }
             a_prev = a_now;
         }
