@@ -339,7 +339,7 @@ __device__ __forceinline__ int actor_pick(const float (&o)[kActorObs], const flo
         S += ex[q];
     }
     if (WANT_PROBS && probs) {
-        const float inv = 1.0f / S;
+        const float inv = __builtin_amdgcn_rcpf(S);
 #pragma unroll
         for (int q = 0; q < SLOTS; ++q)
             if (q < A) probs[q] = ex[q] * inv;
