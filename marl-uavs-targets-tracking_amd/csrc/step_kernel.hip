@@ -1025,7 +1025,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                         nb &= nb - 1;
                         sum += rawl[e * (N + 1) + j];
                     }
-                    r = ncnt_i ? (1.0f - p.coop) * raw + p.coop * sum / (float)ncnt_i : 0.0f;
+                    r = ncnt_i ? fmaf(p.coop * sum, fast_rcp((float)ncnt_i), (1.0f - p.coop) * raw) : 0.0f;      // (v_rcp_f32 for the mean's divide)
                 } else if (p.coop != 0.0f) {   // any N: neighbours re-derived from the post-move poses, self subtracted after
                     v2f sum = splat(0.f), cnt = splat(0.f);
                     const v2f xi2 = splat(x), yi2 = splat(y), zi2 = splat(z);
@@ -1046,7 +1046,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                         cnt += mm;
                     }
                     const float nsum = sum.x + sum.y - raw, ncnt = cnt.x + cnt.y - 1.0f;   // minus self (d = 0)
-                    r = (ncnt > 0.0f) ? (1.0f - p.coop) * raw + p.coop * nsum / ncnt : 0.0f;
+                    r = (ncnt > 0.0f) ? fmaf(p.coop * nsum, fast_rcp(ncnt), (1.0f - p.coop) * raw) : 0.0f;
                 }
             }
             r = fminf(fmaxf(r, -1.0f), 1.0f);   // clip_and_normalize(reward, -1, 1), environment.py:225
