@@ -120,6 +120,16 @@ __device__ __forceinline__ int wave_inclusive_sum(int v)
     return v;
 }
 
+// neighbour masks are 32-bit words up to 32 UAVs (64-bit arithmetic costs two to four instructions per operation)
+__device__ __forceinline__ int mpop(unsigned v) { return __popc(v); }
+__device__ __forceinline__ int mpop(unsigned long long v) { return __popcll(v); }
+__device__ __forceinline__ int mffs(unsigned v) { return __ffs((int)v); }
+__device__ __forceinline__ int mffs(unsigned long long v) { return __ffsll((long long)v); }
+template <int N_> struct NbMaskOf { using type = unsigned long long; };
+template <> struct NbMaskOf<20> { using type = unsigned; };
+template <> struct NbMaskOf<10> { using type = unsigned; };
+template <> struct NbMaskOf<5> { using type = unsigned; };
+
 // Workgroups are dealt round-robin over the 8 XCDs; give consecutive environment
 // groups to one XCD so neighbouring output spans land in the same L2 (speed only).
 __device__ __forceinline__ int xcd_group(int bid, int nwg)
@@ -584,6 +594,8 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     const float abias = act_bias_shape(N_) ? p.act_bias : 0.0f;     // what the table's action slot holds beside the action
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;
+    using NbMask = typename NbMaskOf<N_>::type;      // (specialised shapes up to 32 UAVs: one word)
+    constexpr int kNbBits = 8 * (int)sizeof(NbMask);
 
     // ---- LDS carve (float4 first: the dynamic base is 16-B aligned)
     const int ustride = ustride_of(N), tstride = tstride_of(M);
@@ -716,7 +728,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     };
     unsigned pe_base = 0, pe_tg = 0;        // (thread 0) the reservation in flight; flat [t][b][i] of the pending step
     int pe_mine = 0, pe_slot = 0;
-    unsigned long long pe_nball = 0, pe_later = 0;
+    NbMask pe_nball = 0, pe_later = 0;
     auto pmi_reward_slot = [&](bool has_neighbours, float raw_i) {
         return has_neighbours ? raw_i : fminf(fmaxf((1.0f - p.coop) * raw_i, -1.0f), 1.0f);
     };
@@ -732,9 +744,9 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         store_record(pe_tg, pe_nball, first);
         if (pe_mine) {
             uint2 *dst = p.pairs + first;
-            unsigned long long later = pe_later;
+            NbMask later = pe_later;
             while (later) {                      // ascending j
-                const int j = __ffsll((long long)later) - 1;
+                const int j = mffs(later) - 1;
                 later &= later - 1;
                 *dst++ = make_uint2(pe_tg, pe_tg - (unsigned)i + (unsigned)j);       // {flat index of i, flat index of j}
             }
@@ -745,10 +757,10 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     // neighbour is exactly 1 whatever s_ij is (uav.py:287-288), so both rewards are (1 - a) raw + a raw_partner and the mix
     // kernel never reads the slot.  Such pairs are not emitted (a third of all pairs in the reference's 2000 m box).  `nball`:
     // this UAV's neighbours, `later`: those with a higher index; the neighbours' set sizes were left in LDS ahead of the barrier.
-    auto drop_isolated = [&](unsigned long long nball, unsigned long long later) {
-        if (__popcll(nball) == 1 && later != 0ull &&
-            reinterpret_cast<const int *>(rawl)[e * (N + 1) + (__ffsll((long long)later) - 1)] == 1)
-            later = 0ull;
+    auto drop_isolated = [&](auto nball, decltype(nball) later) {
+        if (mpop(nball) == 1 && later != 0 &&
+            reinterpret_cast<const int *>(rawl)[e * (N + 1) + (mffs(later) - 1)] == 1)
+            later = 0;
         return later;
     };
 
@@ -987,7 +999,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             if (!kSym) raw = fmaf(p.gamma, dupn, fmaf(p.beta, bp, p.alpha * tt));      // (kSym: behind the barrier, once the partners' halves are in)
             if (MODE == UAVTRACK_REWARD_MEAN) rawl[e * (N + 1) + i] = raw;
             // MAAC-R: the size of this UAV's neighbour set, for its neighbours to see behind the barrier (isolated pairs, below)
-            if (MODE == UAVTRACK_REWARD_PMI && kMask) reinterpret_cast<int *>(rawl)[e * (N + 1) + i] = __popcll(nbmask & ~(1ull << i));
+            if (MODE == UAVTRACK_REWARD_PMI && kMask) reinterpret_cast<int *>(rawl)[e * (N + 1) + i] = mpop((NbMask)((NbMask)nbmask & ~((NbMask)1 << i)));
         }
         if (kPipeEmit && tid == 0) {
             // MAAC-R: the reservation made a step ago is taken HERE, ahead of this step's output stores -- its wait
@@ -1017,11 +1029,11 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             float r = raw;
             if (MODE == UAVTRACK_REWARD_MEAN) {
                 if (p.coop != 0.0f && kMask) {   // uav.py:293-310: walk the set bits of the neighbour mask, ascending j
-                    unsigned long long nb = nbmask & ~(1ull << i);
+                    NbMask nb = (NbMask)nbmask & ~((NbMask)1 << i);
                     float sum = 0.0f;
-                    const int ncnt_i = __popcll(nb);
+                    const int ncnt_i = mpop(nb);
                     while (nb) {
-                        const int j = __ffsll((long long)nb) - 1;
+                        const int j = mffs(nb) - 1;
                         nb &= nb - 1;
                         sum += rawl[e * (N + 1) + j];
                     }
@@ -1054,7 +1066,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             // (they read it, and the mix overwrites it with the final value), its FINAL reward (1 - a) raw, clipped
             // (uav.py:290, environment.py:225), when it has none: the mix then neither recomputes nor rewrites it.
             // (unspecialised shapes: the neighbour set is only known in the emission block below, which stores it again)
-            if (MODE == UAVTRACK_REWARD_PMI) r = pmi_reward_slot(kMask ? (nbmask & ~(1ull << i)) != 0ull : true, raw);
+            if (MODE == UAVTRACK_REWARD_PMI) r = pmi_reward_slot(kMask ? (NbMask)((NbMask)nbmask & ~((NbMask)1 << i)) != 0 : true, raw);
 
             ++count;
             // the prefetched action is consumed HERE, ahead of this step's stores: vector-memory operations
@@ -1108,11 +1120,11 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         if (kPoolEmit) {
             unsigned *wg_cnt = covw + 2 * E * CW;          // (a wavefront's LDS operations execute in program order)
             int mine = 0;
-            unsigned long long nball = 0, later = 0;        // all neighbours / neighbours j > i
+            NbMask nball = 0, later = 0;                    // all neighbours / neighbours j > i
             if (active) {
-                nball = nbmask & ~(1ull << i);
-                later = drop_isolated(nball, (i + 1 < 64) ? (nball >> (i + 1)) << (i + 1) : 0ull);
-                mine = __popcll(later);
+                nball = (NbMask)nbmask & ~((NbMask)1 << i);
+                later = drop_isolated(nball, (NbMask)((i + 1 < kNbBits) ? (nball >> (i + 1)) << (i + 1) : 0));
+                mine = mpop(later);
             }
             // every lane's run of slots: an inclusive prefix sum over the wavefront on the cross-lane (DPP) paths -- no trip to the
             // LDS (an LDS atomic per lane and the read-back of the total were three dependent round trips per step)
@@ -1158,7 +1170,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                 store_record(tg_off, nball, first);
                 uint2 *dst = p.pairs + first;
                 while (later) {                      // ascending j
-                    const int j = __ffsll((long long)later) - 1;
+                    const int j = mffs(later) - 1;
                     later &= later - 1;
                     *dst++ = make_uint2(tg_off, tg_off - (unsigned)i + (unsigned)j);
                 }
@@ -1175,11 +1187,11 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             // P3 -> P4 barrier: one barrier of its own is all this block needs)
             if (t > 0 && active) commit_pairs(wg_cnt[1]);
             int mine = 0, slot = 0;
-            unsigned long long nball = 0, later = 0;        // all neighbours / neighbours j > i
+            NbMask nball = 0, later = 0;                    // all neighbours / neighbours j > i
             if (active) {
-                nball = nbmask & ~(1ull << i);
-                later = drop_isolated(nball, (i + 1 < 64) ? (nball >> (i + 1)) << (i + 1) : 0ull);
-                mine = __popcll(later);
+                nball = (NbMask)nbmask & ~((NbMask)1 << i);
+                later = drop_isolated(nball, (NbMask)((i + 1 < kNbBits) ? (nball >> (i + 1)) << (i + 1) : 0));
+                mine = mpop(later);
                 if (mine) slot = (int)atomicAdd(&wg_cnt[0], (unsigned)mine);
             }
             __syncthreads();
