@@ -358,7 +358,11 @@ __device__ __forceinline__ int actor_pick(const float (&o)[kActorObs], const flo
         rng.block = blk;
         rng.valid = true;
     }
-    const uint32_t word = (step & 2) ? ((step & 1) ? rng.r.v[3] : rng.r.v[2]) : ((step & 1) ? rng.r.v[1] : rng.r.v[0]);
+    // word (step & 3) of the block, picked with bit selects: written as ternaries the compiler made it an indexed read of the
+    // block -- which put the block into scratch memory, one dependent scratch load per step in front of the draw
+    const uint32_t m1 = 0u - (step & 1u), m2 = 0u - ((step >> 1) & 1u);
+    const uint32_t w01 = (rng.r.v[0] & ~m1) | (rng.r.v[1] & m1), w23 = (rng.r.v[2] & ~m1) | (rng.r.v[3] & m1);
+    const uint32_t word = (w01 & ~m2) | (w23 & m2);
     const float target = u01(word) * S;
     // first q with cumsum_q > target == number of q with cumsum_q <= target (the sums never decrease);
     // rounding can leave even the last one <= target, hence the clamp
