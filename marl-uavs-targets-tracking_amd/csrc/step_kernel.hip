@@ -933,11 +933,12 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         constexpr bool kMask = (MODE != UAVTRACK_REWARD_RAW) && N_ > 0 && N_ <= 64;
         unsigned long long nbmask = 0;
         unsigned sym_own = 0;                       // (kSym) this lane's own half of the duplicate-term pairs, fixed point
-        // LDS reads of the sweeps run this many peer rows ahead of their use: 2 in the single-wavefront MAAC rollout (a lone wave
-        // has nothing else to cover an LDS round trip with); its MAAC-G, MAAC-R and in-kernel-policy forms have more live state
-        // (neighbour masks, raw rewards, the slot pool, the actor's fragments) and spill with any prefetch (MAAC-G: 0.97 ms per
-        // 200 steps with it, 0.54 without; MAAC-R: 0.73-0.78 against 0.67)
-        constexpr int kPrefetchRows = (LONE && MODE == UAVTRACK_REWARD_RAW && POLICY == kPolicyGiven) ? 2 : 0;
+        // LDS reads of the sweeps run this many peer rows ahead of their use: 2 in the single-wavefront MAAC and MAAC-R rollouts
+        // (a lone wave has nothing else to cover an LDS round trip with; MAAC-R since the end of round 4, when the kernel had
+        // shed enough registers: 256 without scratch, 0.631 -> 0.607 ms per 200 steps).  The MAAC-G and in-kernel-policy forms
+        // have more live state (raw rewards of the neighbours, the actor's fragments) and spill with any prefetch
+        // (MAAC-G: 0.97 ms per 200 steps with it, 0.54 without)
+        constexpr int kPrefetchRows = (LONE && MODE != UAVTRACK_REWARD_MEAN && POLICY == kPolicyGiven) ? 2 : 0;
         if (active) {
             Acc acc;
             // weight of uav.py:165 can be < 1 only near the origin (|rel| <= 1, so |abs| < 2 is necessary).  The branch
