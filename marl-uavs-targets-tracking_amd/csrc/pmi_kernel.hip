@@ -1098,7 +1098,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) pmi_mix_kernel(const MixParams 
                 float den = 0.0f, num = 0.0f;
                 for (unsigned long long m = mask; m; m &= m - 1) {          // ascending j: scipy softmax, uav.py:287
                     const int j = __ffsll((long long)m) - 1;
-                    const float ew = expf(f.scores[slot_of(j)] - mx);
+                    const float ew = __builtin_amdgcn_exp2f((f.scores[slot_of(j)] - mx) * 1.44269504088896340736f);      // exp on v_exp_f32
                     den += ew;
                     num = fmaf(ew, raw_of[j], num);
                 }
@@ -1124,7 +1124,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) pmi_mix_kernel(const MixParams 
             float den = 0.0f, num = 0.0f;
             for (int j = 0; j < N; ++j)
                 if (bit(me, j)) {
-                    const float ew = expf(f.scores[slot_of(j)] - mx);
+                    const float ew = __builtin_amdgcn_exp2f((f.scores[slot_of(j)] - mx) * 1.44269504088896340736f);      // exp on v_exp_f32
                     den += ew;
                     num = fmaf(ew, raw_of[j], num);
                 }
