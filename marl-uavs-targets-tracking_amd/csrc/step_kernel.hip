@@ -243,7 +243,7 @@ __device__ __host__ constexpr bool act_bias_shape(int n_spec) { return n_spec > 
 // Pair sweeps of one UAV, fast path: two agents per packed instruction, no per-agent
 // `j != i` test (self terms are subtracted afterwards).  The uav.py:165/179 weight is 1
 // here (see sweep_weighted).
-template <int N_, int M_, bool Z3, bool NB, int PF, bool SYM = false, bool VC = false>
+template <int N_, int M_, bool Z3, bool NB, int PF, bool SYM = false, bool VC = false, bool NBSEQ = false>
 __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, int i,
                                            const float4 *__restrict__ rowNew, const float4 *__restrict__ rowOld,
                                            const float4 *__restrict__ trow, const v2f *__restrict__ tzrow,
@@ -378,7 +378,9 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
             }
         }
         if (NBF)       // <= 12 pairs: the same packed mask + base-4 digits as the coverage bits (bit order fixed up below)
-            nbf = pk_fma(nbf, splat(4.0f), pk_le_mask<VC>(d2n, nscale, p.le_dp2));
+            // (NBSEQ: on the sequential view, whose lower half -- j < i -- is the post-move poses; the caller keeps that half
+            //  and takes the upper one from the partners, see nb_exchange: the post-move rows are not read at all)
+            nbf = pk_fma(nbf, splat(4.0f), pk_le_mask<VC>(NBSEQ ? d2m : d2n, nscale, p.le_dp2));
         else if (NB)   // cooperative modes (N <= 64): neighbours (d <= dp on post-move poses, uav.py:278) as a bit mask
             nbmask |= ((unsigned long long)(d2n.x <= p.dp2 ? 1u : 0u) | (unsigned long long)(d2n.y <= p.dp2 ? 2u : 0u)) << (2 * jp);
         if (!SYM) {   // (SYM: the duplicate term is shared between the two UAVs of a pair, see sym_dup)
@@ -615,6 +617,11 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     constexpr bool kSym = MODE != UAVTRACK_REWARD_MEAN;
     float *symbase = climb_l + (Z3 ? 2 * UAVTRACK_MAX_CLIMB : 0);
     const int symlen = sym_pose_len(N), symstride = sym_words(N, Z3);
+    // MAAC-R, single-wavefront variants: the neighbour relation (d <= dp on post-move poses) is symmetric and the sequential
+    // view of the peers j < i IS their post-move pose, so each lane tests only those (on the rows the observation sweep
+    // reads anyway) and hands the bit to the partner through one word per UAV: [E][N]
+    constexpr bool kNbSeq = LONE && MODE == UAVTRACK_REWARD_PMI && N_ > 0 && N_ <= 24 && !Z3;
+    unsigned *nbt = reinterpret_cast<unsigned *>(symbase + (kSym ? E * symstride : 0));
 
     const int grp = xcd_group(blockIdx.x, gridDim.x);
     const int env0 = grp * E;
@@ -920,6 +927,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                 }
                 dq[i] = 0; dq[N + i] = 0;
             }
+            if (kNbSeq) nbt[e * N + i] = 0;
         }
         UAVTRACK_STEP_BARRIER();
 
@@ -958,10 +966,18 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                         nbmask |= (unsigned long long)(d2 <= p.dp2 ? 1u : 0u) << j;
                     }
             } else {
-                sweep_fast<N_, M_, Z3, kMask, kPrefetchRows, kSym, kVConst>(p, N, M, i, rowNew, rowOld, tenv, tzrow, covw, cbuf + e * CW,
+                sweep_fast<N_, M_, Z3, kMask, kPrefetchRows, kSym, kVConst, kNbSeq>(p, N, M, i, rowNew, rowOld, tenv, tzrow, covw, cbuf + e * CW,
                                               x, y, z, c, s, ai, xo, yo, zo, co, so, ao, acc, nbmask,
                                               kStepsPerIter == 2 ? (tpar == 0 ? selA : selB) : nullptr,   // (pn == tpar: t0 is even)
                                               uenv, pn ? ~oldw : oldw);
+            }
+            if (kNbSeq) {    // lower half kept, each of its bits handed to the partner; the upper half is what the partners hand in
+                const unsigned lower = (unsigned)nbmask & ((1u << i) - 1u);
+                for (unsigned m = lower; m; m &= m - 1u) atomicOr(&nbt[e * N + __builtin_ctz(m)], 1u << i);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                nbmask = lower | *reinterpret_cast<volatile unsigned *>(&nbt[e * N + i]);
             }
             if (kSym) {      // every active lane, whichever sweep it took: its partners count on its half of the pairs
                 const float *sp = symbase + e * symstride;
@@ -1396,7 +1412,8 @@ size_t lds_bytes_for(int E, int N, int M, bool z3, int reward_mode)
     const size_t CW = cov_words(M), MP = pairs_of(M);
     const size_t f4 = (size_t)E * ustride_of(N) + (size_t)E * tstride_of(M);
     const size_t f = (size_t)E * M + (size_t)E * (N + 1) + (z3 ? (size_t)E * MP * 2 : 0) + (size_t)E * M + 2 * E * CW + 2 + E +
-                     (z3 ? 2 * UAVTRACK_MAX_CLIMB : 0) + (reward_mode != UAVTRACK_REWARD_MEAN ? (size_t)E * sym_words(N, z3) : 0);
+                     (z3 ? 2 * UAVTRACK_MAX_CLIMB : 0) + (reward_mode != UAVTRACK_REWARD_MEAN ? (size_t)E * sym_words(N, z3) : 0) +
+                     (reward_mode == UAVTRACK_REWARD_PMI ? (size_t)E * N : 0);   // (kNbSeq)
     return (f4 * 16 + f * 4 + 15) & ~(size_t)15;   // ustride >= 3 N float4 per env, so ep_sums staging (E N float4) fits
 }
 
