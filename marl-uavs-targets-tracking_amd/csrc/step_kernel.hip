@@ -194,6 +194,28 @@ __device__ __forceinline__ T *at(T *base, unsigned byte_off)
     return (T *)((char *)base + byte_off);   // (char-pointer arithmetic keeps the global address space; an integer round trip would not)
 }
 
+// Outputs are written once and never read back by the launch that writes them: streaming (non-temporal) stores.  Left as
+// ordinary stores they linger dirty in the L2 until evicted, and the single-wavefront headline rollout -- whose one wave per
+// SIMD has nothing to hide a stalled store queue behind -- ran 13 % slower (0.485 vs 0.422 ms per 200 steps, A/B on one
+// box; 65 536 envs: 6.03 vs 5.72 ms; the 3-D 50 x 25 shape: unchanged).
+typedef float v4f_nt __attribute__((ext_vector_type(4)));
+typedef unsigned v2u_nt __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ void out_store(T *ptr, T v)
+{
+    __builtin_nontemporal_store(v, ptr);
+}
+__device__ __forceinline__ void out_store(float4 *ptr, float a, float b, float c, float d)
+{
+    const v4f_nt q = {a, b, c, d};
+    __builtin_nontemporal_store(q, reinterpret_cast<v4f_nt *>(ptr));
+}
+__device__ __forceinline__ void out_store(uint2 *ptr, unsigned a, unsigned b)
+{
+    const v2u_nt q = {a, b};
+    __builtin_nontemporal_store(q, reinterpret_cast<v2u_nt *>(ptr));
+}
+
 // ---- LDS table geometry (float4 units) --------------------------------------------------
 __device__ __host__ __forceinline__ int pairs_of(int n) { return (n + 1) >> 1; }
 // coverage words per environment: 12 target PAIRS per word (two interleaved base-4 digit strings of 12 digits each,
@@ -731,7 +753,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     bool pend = false, pend_got = false;      // a block has been asked for / its base has been collected into pend_base_s
     unsigned pend_base_s = 0;
     auto pool_dummies = [&](unsigned base, unsigned n) {
-        for (unsigned k = (unsigned)tid; k < n; k += (unsigned)nthreads) p.pairs[base + k] = make_uint2(0xFFFFFFFFu, 0u);
+        for (unsigned k = (unsigned)tid; k < n; k += (unsigned)nthreads) out_store(p.pairs + base + k, 0xFFFFFFFFu, 0u);
     };
     unsigned pe_base = 0, pe_tg = 0;        // (thread 0) the reservation in flight; flat [t][b][i] of the pending step
     int pe_mine = 0, pe_slot = 0;
@@ -740,7 +762,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         return has_neighbours ? raw_i : fminf(fmaxf((1.0f - p.coop) * raw_i, -1.0f), 1.0f);
     };
     auto store_record = [&](unsigned tg, unsigned long long nball, unsigned first) {      // N <= 64 (internal.h, nbrec_words)
-        if (N <= 32) *reinterpret_cast<uint2 *>(p.nbrec + (size_t)tg * 2) = make_uint2((unsigned)nball, first);
+        if (N <= 32) out_store(reinterpret_cast<uint2 *>(p.nbrec + (size_t)tg * 2), (unsigned)nball, first);
         else {
             uint32_t *rec = p.nbrec + (size_t)tg * 3;
             rec[0] = (unsigned)nball; rec[1] = (unsigned)(nball >> 32); rec[2] = first;
@@ -755,7 +777,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             while (later) {                      // ascending j
                 const int j = mffs(later) - 1;
                 later &= later - 1;
-                *dst++ = make_uint2(pe_tg, pe_tg - (unsigned)i + (unsigned)j);       // {flat index of i, flat index of j}
+                out_store(dst++, pe_tg, pe_tg - (unsigned)i + (unsigned)j);       // {flat index of i, flat index of j}
             }
         }
     };
@@ -822,7 +844,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                                   [&](int j) { return upos_of(rows, j); },
                                   [&](int k) { return tpos_of(tenv, k); },
                                   [&](int k) { return ncnt[e * M + k]; });
-                if (p.actions_out) *at(p.actions_out + row, g32 * 4u) = act;
+                if (p.actions_out) out_store(at(p.actions_out + row, g32 * 4u), act);
             }
             __syncthreads();   // the policy has read the target table; now it may move
         }
@@ -832,7 +854,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         if (ACTOR) {     // whole wavefronts: the two layers run on the matrix cores (actor.h)
             act = actor_pick<false, actor_tiles(Z3)>(o, p.actor_w, p.actor_hblocks, p.na_total, (uint64_t)(p.env_offset + b),
                                     (uint32_t)count, i, p.greedy_k0, p.greedy_k1, p.actor_mode, nullptr, arng);
-            if (active && p.actions_out) *at(p.actions_out + row, g32 * 4u) = act;
+            if (active && p.actions_out) out_store(at(p.actions_out + row, g32 * 4u), act);
         }
 
         // ---- P1a: targets (target.py:27-60); straight flight, mirror at the walls
@@ -1098,16 +1120,16 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                     if (t > 0) {
                         const int cov = __popc(cov_pending);
                         ecov += cov;
-                        if (p.covered) p.covered[rowb - p.B + b] = cov;          // row t - 1
+                        if (p.covered) out_store(p.covered + (rowb - p.B + b), cov);          // row t - 1
                     }
                     cov_pending = covw[cbuf + e];
                 } else {
                     int cov = 0;
                     for (int w = 0; w < CW; ++w) cov += __popc(covw[cbuf + e * CW + w]);
                     ecov += cov;
-                    if (p.covered) p.covered[rowb + b] = cov;
+                    if (p.covered) out_store(p.covered + (rowb + b), cov);
                 }
-                if (p.done) p.done[rowb + b] = (p.horizon > 0 && count >= p.horizon) ? 1 : 0;
+                if (p.done) out_store(p.done + (rowb + b), (uint8_t)((p.horizon > 0 && count >= p.horizon) ? 1 : 0));
             }
             er += r; ett += tt; ebp += bp; edup += dupn;
 
@@ -1118,16 +1140,16 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             asm volatile("" : "+v"(lane_off4), "+v"(lane_off48));
             if (p.obs) {
                 float4 *op = at(reinterpret_cast<float4 *>(p.obs + row * UAVTRACK_OBS_DIM), lane_off48);
-                op[0] = make_float4(o[0], o[1], o[2], o[3]);
-                op[1] = make_float4(o[4], o[5], o[6], o[7]);
-                op[2] = make_float4(o[8], o[9], o[10], o[11]);
+                out_store(op, o[0], o[1], o[2], o[3]);
+                out_store(op + 1, o[4], o[5], o[6], o[7]);
+                out_store(op + 2, o[8], o[9], o[10], o[11]);
             }
-            if (p.reward) *at(p.reward + row, lane_off4) = r;
+            if (p.reward) out_store(at(p.reward + row, lane_off4), r);
             if (p.terms) {                                    // [t][3][b][i]
                 float *tp = p.terms + 3 * row;
-                *at(tp, lane_off4) = tt;
-                *at(tp + BN, lane_off4) = bp;
-                *at(tp + 2 * BN, lane_off4) = dupn;
+                out_store(at(tp, lane_off4), tt);
+                out_store(at(tp + BN, lane_off4), bp);
+                out_store(at(tp + 2 * BN, lane_off4), dupn);
             }
             a_prev = a_now;
         }
@@ -1190,7 +1212,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                 while (later) {                      // ascending j
                     const int j = mffs(later) - 1;
                     later &= later - 1;
-                    *dst++ = make_uint2(tg_off, tg_off - (unsigned)i + (unsigned)j);
+                    out_store(dst++, tg_off, tg_off - (unsigned)i + (unsigned)j);
                 }
             }
             if (!pend && pool_left < 2 * total && t + 2 < p.T) {   // about to run dry: ask for the next block now, collect it later
@@ -1262,7 +1284,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                     }
                     rec[W] = first;
                 }
-                *at(p.reward + row, g32 * 4u) = pmi_reward_slot(any, raw);      // (the reward slot's MAAC-R content, see P4)
+                out_store(at(p.reward + row, g32 * 4u), pmi_reward_slot(any, raw));      // (the reward slot's MAAC-R content, see P4)
                 if (mine) {
                     uint2 *dst = p.pairs + first;
                     if (N <= 64) {
@@ -1347,7 +1369,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     if (CW == 1 && active && i == 0) {       // the last step's deferred coverage count
         const int cov = __popc(cov_pending);
         ecov += cov;
-        if (p.covered) p.covered[rowb - p.B + b] = cov;
+        if (p.covered) out_store(p.covered + (rowb - p.B + b), cov);
     }
 
     // ---- store state once
