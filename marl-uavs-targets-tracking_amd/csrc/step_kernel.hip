@@ -194,21 +194,19 @@ __device__ __forceinline__ T *at(T *base, unsigned byte_off)
     return (T *)((char *)base + byte_off);   // (char-pointer arithmetic keeps the global address space; an integer round trip would not)
 }
 
-// Outputs are written once and never read back by the launch that writes them: streaming (non-temporal) stores.  Left as
-// ordinary stores they linger dirty in the L2 until evicted, and the single-wavefront headline rollout -- whose one wave per
-// SIMD has nothing to hide a stalled store queue behind -- ran 13 % slower (0.485 vs 0.422 ms per 200 steps, A/B on one
-// box; 65 536 envs: 6.03 vs 5.72 ms; the 3-D 50 x 25 shape: unchanged).
-typedef float v4f_nt __attribute__((ext_vector_type(4)));
+// Outputs are written once and never read back by the launch that writes them.  The arrays a wavefront writes in whole
+// lines -- reward, the three terms, actions, coverage, the MAAC-R records and pairs: 4 or 8 contiguous bytes per lane -- go
+// out as streaming (non-temporal) stores: left as ordinary stores they linger dirty in the L2 until evicted, and the
+// single-wavefront headline rollout, whose one wave per SIMD has nothing to hide a stalled store queue behind, ran 9 % slower
+// (0.467-0.478 vs 0.429-0.432 ms per 200 steps, 30 launches each, A/B on one box).  The observation rows stay ordinary
+// stores: a lane's 48 bytes leave as three 16-byte pieces, the L2 merges them into whole lines, and streamed they reach
+// the memory as partial writes (WRITE_SIZE 1.45 GB per launch instead of 1.07) -- 0.42 ms at best, but 0.54-0.62 ms
+// median once the write queues fill.
 typedef unsigned v2u_nt __attribute__((ext_vector_type(2)));
 template <typename T>
 __device__ __forceinline__ void out_store(T *ptr, T v)
 {
     __builtin_nontemporal_store(v, ptr);
-}
-__device__ __forceinline__ void out_store(float4 *ptr, float a, float b, float c, float d)
-{
-    const v4f_nt q = {a, b, c, d};
-    __builtin_nontemporal_store(q, reinterpret_cast<v4f_nt *>(ptr));
 }
 __device__ __forceinline__ void out_store(uint2 *ptr, unsigned a, unsigned b)
 {
@@ -1140,9 +1138,9 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             asm volatile("" : "+v"(lane_off4), "+v"(lane_off48));
             if (p.obs) {
                 float4 *op = at(reinterpret_cast<float4 *>(p.obs + row * UAVTRACK_OBS_DIM), lane_off48);
-                out_store(op, o[0], o[1], o[2], o[3]);
-                out_store(op + 1, o[4], o[5], o[6], o[7]);
-                out_store(op + 2, o[8], o[9], o[10], o[11]);
+                op[0] = make_float4(o[0], o[1], o[2], o[3]);       // (ordinary stores: see out_store)
+                op[1] = make_float4(o[4], o[5], o[6], o[7]);
+                op[2] = make_float4(o[8], o[9], o[10], o[11]);
             }
             if (p.reward) out_store(at(p.reward + row, lane_off4), r);
             if (p.terms) {                                    // [t][3][b][i]

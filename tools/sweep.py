@@ -10,7 +10,7 @@ ap.add_argument("--n", type=int, default=20); ap.add_argument("--m", type=int, d
 ap.add_argument("--coop", type=float, default=0.0); ap.add_argument("--wgs", default="0")
 ap.add_argument("--policy", default="given", choices=["given", "actor", "actor_step", "greedy"]); ap.add_argument("--hidden", type=int, default=128)
 ap.add_argument("--warm", type=int, default=0, help="untimed launches ahead of the timed ones, no idle gap (loaded clocks: ~150 for 80 ms)");
-ap.add_argument("--reps", type=int, default=5); ap.add_argument("--no-obs", action="store_true"); ap.add_argument("--no-terms", action="store_true"); ap.add_argument("--dim", type=int, default=2)
+ap.add_argument("--reps", type=int, default=5); ap.add_argument("--reset", action="store_true", help="an episode per launch: reset ahead of every launch (what bench.py does)"); ap.add_argument("--no-obs", action="store_true"); ap.add_argument("--no-terms", action="store_true"); ap.add_argument("--dim", type=int, default=2)
 a = ap.parse_args()
 import torch
 import uavtrack
@@ -30,6 +30,7 @@ for wgs in [int(w) for w in a.wgs.split(",")]:
         env.set_actor(uavtrack.ActorMLP(hidden_dim=a.hidden, action_dim=cfg.na_total))
 
     def once(out):
+        if a.reset: env.reset(seed=1)
         if a.policy == "given":
             return env.step_many(act, out=out, want_obs=not a.no_obs, want_terms=not a.no_terms)
         if a.policy == "actor":
@@ -57,5 +58,5 @@ for wgs in [int(w) for w in a.wgs.split(",")]:
     ms = sorted(best)[len(best) // 2]
     rate = a.envs * a.n * a.T / (ms * 1e-3)
     print(f"lib={os.path.basename(a.lib or 'default')} policy={a.policy} B={a.envs} N={a.n} M={a.m} T={a.T} wgs={env.kernel_info()['workgroup']} "
-          f"median {ms:.3f} ms  min {min(best):.3f} ms  {rate/1e9:.2f} G agent-steps/s", flush=True)
+          f"median {ms:.3f} ms  min {min(best):.3f} ms  max {max(best):.3f} ms  {rate/1e9:.2f} G agent-steps/s", flush=True)
     env.close()
