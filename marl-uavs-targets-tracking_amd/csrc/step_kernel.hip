@@ -215,6 +215,8 @@ __device__ __forceinline__ void out_store(uint2 *ptr, unsigned a, unsigned b)
 }
 
 // ---- LDS table geometry (float4 units) --------------------------------------------------
+// observation staging: one 64 x 3 float4 block per wavefront of the E * N lanes (kObsStage)
+__device__ __host__ __forceinline__ int obs_stage_f4(int lanes) { return ((lanes + 63) / 64) * 192; }
 __device__ __host__ __forceinline__ int pairs_of(int n) { return (n + 1) >> 1; }
 // coverage words per environment: 12 target PAIRS per word (two interleaved base-4 digit strings of 12 digits each,
 // accumulated exactly in fp32 by the packed sweep: see sweep_fast)
@@ -623,7 +625,9 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     const int ustride = ustride_of(N), tstride = tstride_of(M);
     float4 *utab = smem4;                        // [E][pairs][2 copies][3]
     float4 *ttab = utab + E * ustride;           // [E][pairs][2]
-    float *fb = reinterpret_cast<float *>(ttab + E * tstride);
+    // (multi-wave groups) staging of a wavefront's observation rows, 64 lanes x 3 float4 each: see kObsStage
+    float4 *ostg = ttab + E * tstride;
+    float *fb = reinterpret_cast<float *>(ostg + obs_stage_f4(E * N));
     float *thd = fb;   fb += E * M;              // [E][M]      target heading
     float *rawl = fb;  fb += E * (N + 1);        // [E][N + 1]  raw reward (cooperative modes), pair-padded
     float *tzf = fb;   if (Z3) fb += E * MP * 2; // [E][pairs] (z0, z1)
@@ -703,6 +707,9 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     // advances uniform base pointers (SGPRs) and each lane adds one 32-bit offset (validate() bounds
     // B * N * 48 below 4 GiB) -- `global_store ... v_off, s[base]` instead of 64-bit vector address math.
     const unsigned g32 = (unsigned)g;
+    // (kObsStage) byte offset of this lane's float4 in the first of its wavefront's three 1 KB runs of an observation row block
+    constexpr bool kObsStage = !LONE;
+    const unsigned ostg_off = (((unsigned)env0 * (unsigned)N + (unsigned)(tid & ~63)) * 3u + (unsigned)(tid & 63)) * 16u;
     unsigned lane_off4 = g32 * 4u, lane_off48 = g32 * (unsigned)(UAVTRACK_OBS_DIM * 4);     // byte offsets of this lane in a [b][i] row of floats / of observations
     size_t row = 0;              // t * B * N: start of this step's [b][i] row in the per-step arrays (uniform)
     size_t rowb = 0;             // t * B
@@ -1136,7 +1143,14 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             //  v_mad_u64_u32 and a v_lshl_add_u64 per array and step -- this way the uniform row base stays in scalar registers
             //  and the stores take the `saddr + 32-bit voffset` form)
             asm volatile("" : "+v"(lane_off4), "+v"(lane_off48));
-            if (p.obs) {
+            if (kObsStage) {
+                if (p.obs) {      // this lane's row into its wavefront's staging block; written out as whole lines behind this block
+                    float4 *sp = ostg + (tid >> 6) * 192 + (tid & 63) * 3;
+                    sp[0] = make_float4(o[0], o[1], o[2], o[3]);
+                    sp[1] = make_float4(o[4], o[5], o[6], o[7]);
+                    sp[2] = make_float4(o[8], o[9], o[10], o[11]);
+                }
+            } else if (p.obs) {
                 float4 *op = at(reinterpret_cast<float4 *>(p.obs + row * UAVTRACK_OBS_DIM), lane_off48);
                 op[0] = make_float4(o[0], o[1], o[2], o[3]);       // (ordinary stores: see out_store)
                 op[1] = make_float4(o[4], o[5], o[6], o[7]);
@@ -1150,6 +1164,28 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                 out_store(at(tp + 2 * BN, lane_off4), dupn);
             }
             a_prev = a_now;
+        }
+        if (kObsStage && p.obs) {
+            // A lane's 48-byte row as three 16-byte stores at a 48-byte stride touches 48 lines per instruction, each in part:
+            // three times the requests the L2 needs for the same bytes, and at a chip-filling batch the observation stores
+            // cost 23 % of the launch (knock-out: 5.5 -> 4.24 ms at 65 536 envs; 12 % at 8192 x 50 x 25 in 3-D).  The rows of
+            // a wavefront are contiguous in the output ([b][i] order = lane order), so they go through a 3 KB staging block:
+            // written row-wise above (stride 12 words: conflict-free per 16 lanes), read back as consecutive float4 and
+            // stored as three contiguous 1 KB runs.  Wavefront-private: no workgroup barrier.  Every lane of the wavefront
+            // takes part (the last wavefront's idle lanes copy rows of its active ones).
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int w0 = tid & ~63;                                           // first lane of this wavefront
+            const int nrow4 = 3 * max(0, min(64, min(EN, envs_here * N) - w0)); // float4 this wavefront's active lanes wrote
+            const float4 *sp = ostg + (tid >> 6) * 192;
+            unsigned oo = ostg_off;
+            asm volatile("" : "+v"(oo));              // (as lane_off4 above: keeps the row base in scalar registers)
+            float4 *op = at(reinterpret_cast<float4 *>(p.obs + row * UAVTRACK_OBS_DIM), oo);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (k * 64 + (tid & 63) < nrow4) op[k * 64] = sp[k * 64 + (tid & 63)];
+            // (the block is rewritten a step later, behind two workgroup barriers)
         }
 
         // ---- MAAC-R only: emit the neighbour pairs (i < j, d <= dp on post-move poses, uav.py:278) this
@@ -1430,7 +1466,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
 size_t lds_bytes_for(int E, int N, int M, bool z3, int reward_mode)
 {
     const size_t CW = cov_words(M), MP = pairs_of(M);
-    const size_t f4 = (size_t)E * ustride_of(N) + (size_t)E * tstride_of(M);
+    const size_t f4 = (size_t)E * ustride_of(N) + (size_t)E * tstride_of(M) + obs_stage_f4(E * N);
     const size_t f = (size_t)E * M + (size_t)E * (N + 1) + (z3 ? (size_t)E * MP * 2 : 0) + (size_t)E * M + 2 * E * CW + 2 + E +
                      (z3 ? 2 * UAVTRACK_MAX_CLIMB : 0) + (reward_mode != UAVTRACK_REWARD_MEAN ? (size_t)E * sym_words(N, z3) : 0) +
                      (reward_mode == UAVTRACK_REWARD_PMI ? (size_t)E * N : 0);   // (kNbSeq)
