@@ -9,12 +9,12 @@ import json
 import sys
 
 FLOORS = {   # cfg substring -> (key, floor)
-    "4096x20x10 2D raw (timed region)": ("frac", 0.455),
-    "configs[2] MAAC-R, PMI hidden 128": ("G", 10.9),
+    "4096x20x10 2D raw (timed region)": ("frac", 0.50),
+    "configs[2] MAAC-R, PMI hidden 128": ("G", 11.2),
     "configs[2] MAAC-R, PMI hidden 64": ("G", 14.9),
     "configs[2] MAAC-R dense": ("G", 5.6),
     "configs[3] 3-D": ("frac", 0.31),
-    "chip-filling": ("frac", 0.60),
+    "chip-filling": ("frac", 0.64),
 }
 
 
