@@ -709,6 +709,7 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
     const unsigned g32 = (unsigned)g;
     // (kObsStage) byte offset of this lane's float4 in the first of its wavefront's three 1 KB runs of an observation row block
     constexpr bool kObsStage = !LONE;
+    constexpr bool kObsEarly = kObsStage && POLICY != kPolicyActor;
     const unsigned ostg_off = (((unsigned)env0 * (unsigned)N + (unsigned)(tid & ~63)) * 3u + (unsigned)(tid & 63)) * 16u;
     unsigned lane_off4 = g32 * 4u, lane_off48 = g32 * (unsigned)(UAVTRACK_OBS_DIM * 4);     // byte offsets of this lane in a [b][i] row of floats / of observations
     size_t row = 0;              // t * B * N: start of this step's [b][i] row in the per-step arrays (uniform)
@@ -1032,6 +1033,14 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             o[9] = x * p.inv_dc;
             o[10] = y * p.inv_dc;
             o[11] = ai * p.inv_na_total;
+            // (kObsStage) the row goes into the wavefront's staging block as soon as it exists: twelve registers fewer are
+            // live across the barrier and the reward phase (the in-kernel actor reads o[] at the next step and keeps them)
+            if (kObsEarly && p.obs) {
+                float4 *sp = ostg + (tid >> 6) * 192 + (tid & 63) * 3;
+                sp[0] = make_float4(o[0], o[1], o[2], o[3]);
+                sp[1] = make_float4(o[4], o[5], o[6], o[7]);
+                sp[2] = make_float4(o[8], o[9], o[10], o[11]);
+            }
 
             // ---- raw reward terms, clipped and normalised (environment.py:207-220)
             float d_bdr = fminf(fminf(x, p.x_max - x), fminf(y, p.y_max - y));
@@ -1143,7 +1152,8 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             //  v_mad_u64_u32 and a v_lshl_add_u64 per array and step -- this way the uniform row base stays in scalar registers
             //  and the stores take the `saddr + 32-bit voffset` form)
             asm volatile("" : "+v"(lane_off4), "+v"(lane_off48));
-            if (kObsStage) {
+            if (kObsEarly) {      // (staged in P3)
+            } else if (kObsStage) {
                 if (p.obs) {      // this lane's row into its wavefront's staging block; written out as whole lines behind this block
                     float4 *sp = ostg + (tid >> 6) * 192 + (tid & 63) * 3;
                     sp[0] = make_float4(o[0], o[1], o[2], o[3]);
