@@ -15,7 +15,12 @@
  *    fp32 / int32 / uint8 as declared.  The library keeps no reference to them
  *    after the stream work it enqueued has run.
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
- *    Every call is asynchronous on that stream; nothing synchronises the host.
+ *    The stepping and reset calls are asynchronous on that stream and never
+ *    synchronise the host or allocate: they can be captured into a HIP graph.
+ *    (MAAC-R scratch is sized for cfg.horizon steps when the weights are set;
+ *    only a longer call grows it -- a synchronisation -- and under capture
+ *    that call is refused instead.)  The calls that DO synchronise say so:
+ *    the weight uploads, the info / accounting queries, uavtrack_step_host.
  *  - a handle is owned by one host thread at a time (like the reference's
  *    single-threaded Environment); one handle per GPU, one process per GPU.
  *  - batch layout is struct-of-arrays: UAV arrays are [n_envs][n_uav], target
@@ -264,6 +269,37 @@ int uavtrack_run_actor(uavtrack_env *env, int32_t T, uint64_t seed, int32_t mode
  * call's T steps at tpos[t] -- until it is replaced; it must hold capacity_steps >= the largest T passed while it
  * is set (checked).  tpos = NULL switches the output off (the default). */
 int uavtrack_set_target_trace(uavtrack_env *env, float *tpos, int32_t capacity_steps);
+
+/* Optional extra output of every stepping entry point, like the target trace: raw [T][B][N] = uav.raw_reward of every
+ * UAV after each step -- alpha * tracking + beta * boundary + gamma * duplicate of the clipped, normalised terms
+ * (environment.py:211-219), BEFORE the cooperative sharing of environment.py:222-226.  The reference keeps it as a public
+ * attribute of each UAV (uav.py:50).  Row t of a call's T steps at raw + t * B * N; capacity_steps >= the largest T passed
+ * while the buffer is set (checked); raw = NULL switches the output off (the default). */
+int uavtrack_set_raw_reward_output(uavtrack_env *env, float *raw, int32_t capacity_steps);
+
+/* Environment.step (environment.py:120-164) for a caller that lives on the HOST, the way the reference's own training
+ * loop calls it (train.py:160-185: a Python list of actions in; next_states, the reward dict and the covered count out,
+ * one environment, one step at a time).  actions_host [B][N] int32 is a HOST pointer; the results are left in a
+ * library-owned, page-locked host block that the kernels write directly through its device mapping (no device-to-host
+ * copy call), together with a copy of the state as it stands behind the step (what Environment.step appends to
+ * `position`, environment.py:150-155, and what callers read as uav.x / target.x).  `out` receives HOST pointers into that
+ * block; they stay valid, and are overwritten, until the next uavtrack_step_host or uavtrack_destroy on the handle.
+ * This entry point SYNCHRONISES `stream` before it returns (the one stepping call that does): it is meant for batches
+ * of one or a few environments -- the drop-in adapter -- where a step is bound by the launch and the synchronisation,
+ * not by the kernel.  Batched rollouts use uavtrack_step / uavtrack_step_many on device buffers. */
+typedef struct uavtrack_host_step {
+    const float   *obs;        /* [B][N][12] next_states                         (environment.py:144) */
+    const float   *reward;     /* [B][N]     reward['rewards']                   (environment.py:158) */
+    const float   *terms;      /* [3][B][N]  the three normalised terms          (environment.py:159-161) */
+    const float   *raw;        /* [B][N]     uav.raw_reward                      (environment.py:219) */
+    const int32_t *covered;    /* [B]        covered_targets                     (environment.py:146) */
+    const uint8_t *done;       /* [B]        step_count >= horizon */
+    const float   *ux, *uy, *uz, *uh;   /* [B][N] UAV poses behind the step (uz NULL in 2-D) */
+    const int32_t *ua;                  /* [B][N] the actions just applied (uav.a) */
+    const float   *tx, *ty, *tz, *th;   /* [B][M] target poses behind the step (tz NULL in 2-D) */
+    const int32_t *step_count;          /* [B] */
+} uavtrack_host_step;
+int uavtrack_step_host(uavtrack_env *env, const int32_t *actions_host, uavtrack_host_step *out, void *stream);
 
 /* MAAC-R accounting for reports: out[0] = neighbour pairs the stepping entry points have handed to the PMI network
  * since the handle was created (each unordered pair once per step).  A pair of UAVs that are each other's ONLY

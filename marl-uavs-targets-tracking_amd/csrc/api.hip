@@ -103,6 +103,8 @@ void free_state(uavtrack_env *env)
                     env->obs_tmp, env->rsum, env->inf_obs, env->inf_pairs, env->pmi_flags};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (env->host_blk) (void)hipHostFree(env->host_blk);
+    env->host_blk = env->host_blk_dev = nullptr;
 }
 
 int validate(const uavtrack_config &c)
@@ -152,6 +154,22 @@ int ensure_pmi_scratch(uavtrack_env *env, int32_t steps, hipStream_t st)
     if (cap > idx_cap) cap = idx_cap;
     if (cap < 1) cap = 1;
     if (cap > steps) cap = steps;
+    // the counters first, each guarded on its own: a failure between two of them must not leave a later call with a null one
+    const bool fresh_counters = !env->pair_count || !env->pair_total || !env->pmi_flags;
+    if (cap <= env->pmi_steps_cap && !fresh_counters) return 0;
+    {   // Growing means a host synchronisation and device allocations: neither may happen while `st` is being captured into a
+        // HIP graph.  uavtrack_set_pmi_weights sizes the scratch for cfg.horizon steps, so only a call longer than an
+        // episode can get here; under capture it is refused with a message of its own instead of invalidating the capture.
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail("MAAC-R scratch must grow to %lld steps per chunk (it holds %d) but the stream is being captured into a graph: "
+                        "issue one call of this length outside the capture first, or keep T <= cfg.horizon (sized at "
+                        "uavtrack_set_pmi_weights)", (long long)cap, env->pmi_steps_cap);
+        (void)hipGetLastError();
+    }
+    if (!env->pair_count) { HIP_TRY(dmalloc(&env->pair_count, 2)); HIP_TRY(hipMemsetAsync(env->pair_count, 0, 2 * sizeof(unsigned), st)); }
+    if (!env->pair_total) { HIP_TRY(dmalloc(&env->pair_total, 1)); HIP_TRY(hipMemsetAsync(env->pair_total, 0, sizeof(unsigned long long), st)); }
+    if (!env->pmi_flags) { HIP_TRY(dmalloc(&env->pmi_flags, 2)); HIP_TRY(hipMemsetAsync(env->pmi_flags, 0, 2 * sizeof(unsigned), st)); }
     if (cap <= env->pmi_steps_cap) return 0;
     HIP_TRY(hipStreamSynchronize(st));
     // the larger buffers first, the old ones released only once all of them exist: a failed allocation leaves the handle
@@ -175,14 +193,6 @@ int ensure_pmi_scratch(uavtrack_env *env, int32_t steps, hipStream_t st)
     for (void *q : old)
         if (q) (void)hipFree(q);
     env->pairs = n_pairs; env->scores = n_scores; env->nbrec = n_rec; env->obs_tmp = n_obs; env->rsum = n_rsum;
-    if (!env->pair_count) {
-        HIP_TRY(dmalloc(&env->pair_count, 1));
-        HIP_TRY(hipMemsetAsync(env->pair_count, 0, sizeof(unsigned), st));
-        HIP_TRY(dmalloc(&env->pair_total, 1));
-        HIP_TRY(hipMemsetAsync(env->pair_total, 0, sizeof(unsigned long long), st));
-        HIP_TRY(dmalloc(&env->pmi_flags, 2));
-        HIP_TRY(hipMemsetAsync(env->pmi_flags, 0, 2 * sizeof(unsigned), st));
-    }
     env->pmi_steps_cap = (int32_t)cap;
     return 0;
 }
@@ -249,6 +259,36 @@ void fold_constants(const uavtrack_config &c, StepParams &p, float *climb_c, flo
     }
 }
 
+// ---- Environment.step for a HOST caller (uavtrack_step_host) ----------------------------------------------------
+// the state slab, as it stands behind the step, into the host block (one launch: a small device-to-host hipMemcpyAsync
+// costs more than a kernel that writes the mapped block directly)
+__global__ void __launch_bounds__(256) state_snapshot_kernel(const uint32_t *__restrict__ slab, uint32_t *__restrict__ dst, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < n) __builtin_nontemporal_store(slab[k], dst + k);
+}
+
+struct HostLayout {      // offsets into the host block, in 4-byte units
+    size_t actions, obs, reward, terms, raw, covered, done, state, total;
+};
+HostLayout host_layout(const uavtrack_config &c)
+{
+    const size_t BN = (size_t)c.n_envs * c.n_uav, B = (size_t)c.n_envs;
+    HostLayout L;
+    size_t o = 0;
+    auto take = [&](size_t n) { const size_t at = o; o += (n + 3) & ~(size_t)3; return at; };      // 16-byte aligned pieces
+    L.actions = take(BN);
+    L.obs = take(BN * UAVTRACK_OBS_DIM);
+    L.reward = take(BN);
+    L.terms = take(3 * BN);
+    L.raw = take(BN);
+    L.covered = take(B);
+    L.done = take((B + 3) / 4);
+    L.state = take(state_slab_floats(c.n_envs, c.n_uav, c.m_targets, c.dim == 3));
+    L.total = o;
+    return L;
+}
+
 }  // namespace
 
 extern "C" {
@@ -291,7 +331,8 @@ int uavtrack_create(const uavtrack_config *cfg, uavtrack_env **out)
     env->n_cus = prop.multiProcessorCount;
     if (env->geo.wgs == 0) {
         delete env;
-        return fail("uavtrack_create: no workgroup geometry for n_uav=%d", cfg->n_uav);
+        return fail("uavtrack_create: no workgroup geometry for n_uav=%d, m_targets=%d: one environment's tables must fit the %zu KiB of "
+                    "LDS of a CU", cfg->n_uav, cfg->m_targets, kLdsMax / 1024);
     }
     // specialised swarms of up to 64 UAVs count neighbours in the high part of an exact fp32 integer sum (step_kernel.hip
     // act_bias_shape): n_uav * (K + na * nc) must stay below 2^24 there (the generic kernel keeps a separate count)
@@ -302,12 +343,12 @@ int uavtrack_create(const uavtrack_config *cfg, uavtrack_env **out)
     }
     env->base.E = env->geo.envs_per_wg;
     env->geo_short = cfg->reward_mode == UAVTRACK_REWARD_PMI ? plan_geometry(*cfg, prop.multiProcessorCount * 4, false) : env->geo;
-    if (env->geo_short.wgs == 0 || env->geo_short.lds_bytes > 64 * 1024) env->geo_short = env->geo;
-    if (env->geo.lds_bytes > 64 * 1024) {
+    if (env->geo_short.wgs == 0 || env->geo_short.lds_bytes > kLdsMax) env->geo_short = env->geo;
+    if (env->geo.lds_bytes > kLdsMax) {      // (plan_geometry already turns such shapes away: a second line of defence)
         const size_t need = env->geo.lds_bytes;
         delete env;
-        return fail("uavtrack_create: LDS need %zu B exceeds the 64 KiB this build launches with (n_uav=%d, m_targets=%d)", need, cfg->n_uav,
-                    cfg->m_targets);
+        return fail("uavtrack_create: one environment's tables need %zu B of LDS, a gfx950 CU has %zu (n_uav=%d, m_targets=%d)", need,
+                    kLdsMax, cfg->n_uav, cfg->m_targets);
     }
 
     const size_t nfl = state_slab_floats(cfg->n_envs, cfg->n_uav, cfg->m_targets, cfg->dim == 3);
@@ -449,17 +490,13 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
     const size_t x6_off = (n_dev + 3) & ~(size_t)3, x6_len = pmi_x6_floats(hp);     // the bf16 planes, 16-B aligned
     const size_t l1_off = x6_off + x6_len, l1_len = pmi_l1_floats(hp);               // the branch layers' f16 planes behind them
     const size_t t3_off = l1_off + l1_len, t3_len = pmi_t3_floats(hp);               // ... and fc1 block-scaled (pmi_score_t3_kernel)
-    if (env->pmi.n_floats != n_dev) {
-        HIP_TRY(hipStreamSynchronize(st));
-        if (env->pmi.blob) (void)hipFree(env->pmi.blob);
-        env->pmi = PmiWeights();
-        HIP_TRY(dmalloc(&env->pmi.blob, t3_off + t3_len));
-    }
+
+    // ---- everything the host can decide comes FIRST: a call that fails leaves the handle's previous weights in place
     bool h3_ok = t3_len != 0;
     float s1 = 1.0f, tw = 1.0f;
     float rng_inv[3] = {0.0f, 0.0f, 0.0f};
-    {   // fc1 goes up in the scorer's register order; the copy has completed before `packed` dies
-        std::vector<float> padded(n_dev, 0.0f), packed(n_dev);
+    std::vector<float> padded(n_dev, 0.0f), packed(n_dev);
+    {
         const float *src = folded;
         float *dst = padded.data();
         auto rows = [&](size_t nrows, size_t in_w, size_t out_w) {      // nrows rows of in_w floats -> rows of out_w
@@ -477,96 +514,110 @@ int uavtrack_set_pmi_weights(uavtrack_env *env, const float *folded, size_t n_fl
         rows(1, H, HP);                           // b1[H]
         rows(1, H, HP);                           // w2[H]
         rows(1, 1, 1);                            // b2
-        pack_pmi_blob(padded.data(), packed.data(), hp);
-        HIP_TRY(hipMemcpyAsync(env->pmi.blob, packed.data(), n_dev * 4, hipMemcpyHostToDevice, st));
-        std::vector<uint16_t> planes(x6_len * 2);
-        if (x6_len) {
-            pack_pmi_x6(padded.data(), planes.data(), hp);
-            HIP_TRY(hipMemcpyAsync(env->pmi.blob + x6_off, planes.data(), x6_len * 4, hipMemcpyHostToDevice, st));
-        }
-        // The f16 x 3 scorer (pmi_score_t3_kernel) needs every MFMA operand inside f16's range (65504): the fc1 weights
-        // are known here, the branch activations are bounded from the ranges of the observation products x = la_i * la_j
-        // (uav.py:156-197: normalised offsets and action differences within [-1, 1], heading terms within +-(1 + v_t/v_u),
-        // positions / dc taken up to three field lengths outside the box).  A network beyond half that range keeps the
-        // bf16 x 6 kernel (bf16 has fp32's exponent).
-        if (h3_ok) {
-            const uavtrack_config &c = env->cfg;
-            const double vr = 1.0 + c.t_v_max / c.u_v_max, pos = 4.0 * std::fmax(c.x_max, c.y_max) / c.dc;
-            const double xb[12] = {1, 1, 4, 4, 1, 1, 1, vr * vr, vr * vr, pos * pos, pos * pos, 1};
-            const float *pw = padded.data();
-            double act_max = 0.0, w_max = 0.0, w1_max = 0.0;
-            double gain[3] = {0.0, 0.0, 0.0}, bias[3] = {0.0, 0.0, 0.0};      // per branch: max_u sum_k |w_uk|, max_u |b_u|
-            const int fan[3] = {5, 4, 3};
-            int k0 = 0;
-            for (int br = 0; br < 3; ++br) {              // W[fan][HP] then b[HP]
-                for (size_t u = 0; u < HP; ++u) {
-                    double a = std::fabs(pw[(size_t)fan[br] * HP + u]), gsum = 0.0;
-                    bias[br] = std::fmax(bias[br], a);
-                    for (int k = 0; k < fan[br]; ++k) {
-                        a += std::fabs(pw[(size_t)k * HP + u]) * xb[k0 + k];
-                        gsum += std::fabs(pw[(size_t)k * HP + u]);
-                    }
-                    gain[br] = std::fmax(gain[br], gsum);
-                    act_max = std::fmax(act_max, a);
-                }
-                pw += (size_t)(fan[br] + 1) * HP;
-                k0 += fan[br];
-            }
-            for (size_t k = 0; k < 3 * HP * HP; ++k) w1_max = std::fmax(w1_max, std::fabs(pw[k]));
-            w_max = w1_max;
-            for (size_t k = 0; k < 15 * HP; ++k) w_max = std::fmax(w_max, std::fabs(padded[k]));      // the branch layers (MFMA operands of pmi_score_t3_kernel)
-            w_max = std::fmax(w_max, pos * pos);                                                         // ... and their inputs
-            h3_ok = std::isfinite(act_max) && act_max < 32000.0 && w_max < 32000.0;
-            // Block scales of the t3 planes, powers of two: T * max |fc1 weight| just below 32000 (the weights are known
-            // exactly); S1 * (activation bound) below 512 -- the bound comes from nominal observation ranges, and the
-            // uav.py:165 weight lets a UAV next to the origin exceed them, so the activations keep a factor 128 of
-            // headroom to f16's 65504 (the unscaled h3 planes have 65504 / bound).  Remainders x - f16(x) of values within
-            // 2^-12 (activations) / 2^-18 (weights) of those sizes are normal f16 numbers.
-            auto scale_for = [](double bound, double target) {
-                int e = 15;
-                if (bound > 0.0) e = (int)std::floor(std::log2(target / bound));
-                return std::ldexp(1.0f, e < -6 ? -6 : (e > 15 ? 15 : e));
-            };
-            s1 = scale_for(act_max, 512.0);
-            tw = scale_for(w1_max, 32000.0);
-            // The run-time watch of the f16 kernel (pmi_kernel.hip, PmiParams::rng_inv).  The bounds above come from NOMINAL
-            // observation ranges; the uav.py:165 weight 1 / min(d, 1) lets a UAV next to the origin exceed them without
-            // limit.  An activation of branch br stays below 60000 / S1 while |x| <= (60000 / S1 - max|b|) / max_u sum_k|w_uk|
-            // over the branch's inputs, and an input splits into normal f16 planes below 30000 (its remainder is scaled by 2^11):
-            // the kernel compares the largest |x| of a tile with the smaller of the two and has the chunk re-scored by the
-            // bf16 kernel when it is exceeded.
-            for (int br = 0; br < 3; ++br) {
-                double lim = 30000.0;
-                if (gain[br] > 0.0) lim = std::fmin(lim, (60000.0 / (double)s1 - bias[br]) / gain[br]);
-                rng_inv[br] = lim > 0.0 ? (float)(1.0 / lim) : INFINITY;
-            }
-        }
-        std::vector<uint16_t> planes1(l1_len * 2);
-        if (h3_ok) {
-            pack_pmi_l1(padded.data(), planes1.data(), hp, s1);
-            HIP_TRY(hipMemcpyAsync(env->pmi.blob + l1_off, planes1.data(), l1_len * 4, hipMemcpyHostToDevice, st));
-        }
-        std::vector<uint16_t> planes3t;
-        if (h3_ok) {
-            planes3t.resize(t3_len * 2);
-            pack_pmi_t3(padded.data(), planes3t.data(), hp, tw);
-            HIP_TRY(hipMemcpyAsync(env->pmi.blob + t3_off, planes3t.data(), t3_len * 4, hipMemcpyHostToDevice, st));
-        }
-        HIP_TRY(hipStreamSynchronize(st));
     }
-    env->pmi.x6 = x6_len ? env->pmi.blob + x6_off : nullptr;
-    env->pmi.l1 = h3_ok ? env->pmi.blob + l1_off : nullptr;
-    env->pmi.t3 = h3_ok ? env->pmi.blob + t3_off : nullptr;
+    // The f16 x 3 scorer (pmi_score_t3_kernel) needs every MFMA operand inside f16's range (65504): the fc1 weights
+    // are known here, the branch activations are bounded from the ranges of the observation products x = la_i * la_j
+    // (uav.py:156-197: normalised offsets and action differences within [-1, 1], heading terms within +-(1 + v_t/v_u),
+    // positions / dc taken up to three field lengths outside the box).  A network beyond half that range keeps the
+    // bf16 x 6 kernel (bf16 has fp32's exponent).
+    if (h3_ok) {
+        const uavtrack_config &c = env->cfg;
+        const double vr = 1.0 + c.t_v_max / c.u_v_max, pos = 4.0 * std::fmax(c.x_max, c.y_max) / c.dc;
+        const double xb[12] = {1, 1, 4, 4, 1, 1, 1, vr * vr, vr * vr, pos * pos, pos * pos, 1};
+        const float *pw = padded.data();
+        double act_max = 0.0, w_max = 0.0, w1_max = 0.0;
+        double gain[3] = {0.0, 0.0, 0.0}, bias[3] = {0.0, 0.0, 0.0};      // per branch: max_u sum_k |w_uk|, max_u |b_u|
+        const int fan[3] = {5, 4, 3};
+        int k0 = 0;
+        for (int br = 0; br < 3; ++br) {              // W[fan][HP] then b[HP]
+            for (size_t u = 0; u < HP; ++u) {
+                double a = std::fabs(pw[(size_t)fan[br] * HP + u]), gsum = 0.0;
+                bias[br] = std::fmax(bias[br], a);
+                for (int k = 0; k < fan[br]; ++k) {
+                    a += std::fabs(pw[(size_t)k * HP + u]) * xb[k0 + k];
+                    gsum += std::fabs(pw[(size_t)k * HP + u]);
+                }
+                gain[br] = std::fmax(gain[br], gsum);
+                act_max = std::fmax(act_max, a);
+            }
+            pw += (size_t)(fan[br] + 1) * HP;
+            k0 += fan[br];
+        }
+        for (size_t k = 0; k < 3 * HP * HP; ++k) w1_max = std::fmax(w1_max, std::fabs(pw[k]));
+        w_max = w1_max;
+        for (size_t k = 0; k < 15 * HP; ++k) w_max = std::fmax(w_max, std::fabs(padded[k]));      // the branch layers (MFMA operands of pmi_score_t3_kernel)
+        w_max = std::fmax(w_max, pos * pos);                                                         // ... and their inputs
+        h3_ok = std::isfinite(act_max) && act_max < 32000.0 && w_max < 32000.0;
+        // Block scales of the t3 planes, powers of two: T * max |fc1 weight| just below 32000 (the weights are known
+        // exactly); S1 * (activation bound) below 512 -- the bound comes from nominal observation ranges, and the
+        // uav.py:165 weight lets a UAV next to the origin exceed them, so the activations keep a factor 128 of
+        // headroom to f16's 65504 (the unscaled h3 planes have 65504 / bound).  Remainders x - f16(x) of values within
+        // 2^-12 (activations) / 2^-18 (weights) of those sizes are normal f16 numbers.
+        auto scale_for = [](double bound, double target) {
+            int e = 15;
+            if (bound > 0.0) e = (int)std::floor(std::log2(target / bound));
+            return std::ldexp(1.0f, e < -6 ? -6 : (e > 15 ? 15 : e));
+        };
+        s1 = scale_for(act_max, 512.0);
+        tw = scale_for(w1_max, 32000.0);
+        // The run-time watch of the f16 kernel (pmi_kernel.hip, PmiParams::rng_inv).  The bounds above come from NOMINAL
+        // observation ranges; the uav.py:165 weight 1 / min(d, 1) lets a UAV next to the origin exceed them without
+        // limit.  An activation of branch br stays below 60000 / S1 while |x| <= (60000 / S1 - max|b|) / max_u sum_k|w_uk|
+        // over the branch's inputs, and an input splits into normal f16 planes below 30000 (its remainder is scaled by 2^11):
+        // the kernel compares the largest |x| of a tile with the smaller of the two and has the chunk re-scored by the
+        // bf16 kernel when it is exceeded.
+        for (int br = 0; br < 3; ++br) {
+            double lim = 30000.0;
+            if (gain[br] > 0.0) lim = std::fmin(lim, (60000.0 / (double)s1 - bias[br]) / gain[br]);
+            rng_inv[br] = lim > 0.0 ? (float)(1.0 / lim) : INFINITY;
+        }
+    }
+    // a pinned scorer (uavtrack_set_pmi_scheme) that cannot take these weights: refused before anything is replaced
+    if (!pmi_scheme_fits(hp, h3_ok, env->pmi_scheme))
+        return fail("uavtrack_set_pmi_weights: these weights (hidden %d%s) cannot run on the pinned scorer scheme %d "
+                    "(uavtrack_set_pmi_scheme); pin UAVTRACK_PMI_AUTO or a scheme that takes them; the previous weights stay loaded",
+                    hidden, h3_ok ? "" : ", beyond f16's range", env->pmi_scheme);
+    pack_pmi_blob(padded.data(), packed.data(), hp);
+    std::vector<uint16_t> planes(x6_len * 2), planes1(h3_ok ? l1_len * 2 : 0), planes3t(h3_ok ? t3_len * 2 : 0);
+    if (x6_len) pack_pmi_x6(padded.data(), planes.data(), hp);
+    if (h3_ok) {
+        pack_pmi_l1(padded.data(), planes1.data(), hp, s1);
+        pack_pmi_t3(padded.data(), planes3t.data(), hp, tw);
+    }
+
+    // ---- device side: a blob of another size is allocated BEFORE the old one goes; the uploads are complete before the
+    //      host vectors die and before the new weights are published in the handle
+    float *blob = env->pmi.blob;
+    const bool fresh = env->pmi.n_floats != n_dev || !blob;
+    HIP_TRY(hipStreamSynchronize(st));          // (launches that still read the current weights)
+    if (fresh) {
+        blob = nullptr;
+        HIP_TRY(dmalloc(&blob, t3_off + t3_len));
+    }
+    hipError_t e = hipMemcpyAsync(blob, packed.data(), n_dev * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && x6_len) e = hipMemcpyAsync(blob + x6_off, planes.data(), x6_len * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && h3_ok) e = hipMemcpyAsync(blob + l1_off, planes1.data(), l1_len * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && h3_ok) e = hipMemcpyAsync(blob + t3_off, planes3t.data(), t3_len * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        if (fresh) (void)hipFree(blob);          // (an in-place upload that failed half way cannot be undone: the handle loses its weights)
+        else { (void)hipFree(env->pmi.blob); env->pmi = PmiWeights(); }
+        (void)hipGetLastError();
+        return fail("uavtrack_set_pmi_weights: upload failed: %s", hipGetErrorString(e));
+    }
+    if (fresh && env->pmi.blob) (void)hipFree(env->pmi.blob);
+    env->pmi.blob = blob;
+    env->pmi.x6 = x6_len ? blob + x6_off : nullptr;
+    env->pmi.l1 = h3_ok ? blob + l1_off : nullptr;
+    env->pmi.t3 = h3_ok ? blob + t3_off : nullptr;
     env->pmi.t3_s1 = s1;
     env->pmi.t3_t = tw;
     for (int k = 0; k < 3; ++k) env->pmi.rng_inv[k] = rng_inv[k];
     env->pmi.hidden = hp;
     env->pmi.n_floats = n_dev;
-    if (ensure_pmi_scratch(env, 1, st)) return 1;
-    if (!pmi_scheme_available(env, env->pmi_scheme))
-        return fail("uavtrack_set_pmi_weights: these weights (hidden %d%s) cannot run on the pinned scorer scheme %d "
-                    "(uavtrack_set_pmi_scheme); pin UAVTRACK_PMI_AUTO or a scheme that takes them",
-                    hidden, h3_ok ? "" : ", beyond f16's range", env->pmi_scheme);
+    // scratch for an episode's worth of deferred scoring (bounded by UAVTRACK_PMI_SCRATCH_MB): the stepping calls then never
+    // allocate or synchronise, whatever their length up to cfg.horizon -- which also makes them capturable into a HIP graph
+    if (ensure_pmi_scratch(env, env->cfg.horizon > 0 ? env->cfg.horizon : 1, st)) return 1;
     return 0;
 }
 
@@ -650,9 +701,12 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (env->tpos && T > env->tpos_steps)
         return fail("%s: T = %d exceeds the %d steps the target-trace buffer holds (uavtrack_set_target_trace)", who, T, env->tpos_steps);
+    if (env->raw_out && T > env->raw_steps)
+        return fail("%s: T = %d exceeds the %d steps the raw-reward buffer holds (uavtrack_set_raw_reward_output)", who, T, env->raw_steps);
     StepParams p = env->base;
     p.actions = actions;
     p.tpos = env->tpos;
+    p.raw = env->raw_out;
     p.obs = obs; p.reward = reward; p.terms = terms; p.nbrec = nullptr;
     p.covered = covered; p.done = done; p.ep_sums = ep_sums;
     p.pairs = nullptr; p.pair_count = nullptr; p.pair_total = nullptr;
@@ -701,6 +755,7 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
         p.covered = covered_t;
         p.done = done ? done + (size_t)t0 * c.n_envs : nullptr;
         p.tpos = env->tpos ? env->tpos + (size_t)t0 * c.n_envs * c.m_targets : nullptr;
+        p.raw = env->raw_out ? env->raw_out + (size_t)t0 * BN : nullptr;
         // (short launches: 4-wave groups; long ones: the handle's geometry where its kernel variant exists -- launch_rollout)
         const Geometry *geo = n < kPmiShortLaunch ? &env->geo_short : nullptr;
         HIP_TRY(timed_launch(env, UAVTRACK_PROF_ROLLOUT, st, [&] { return launch_rollout(env, p, st, pol.policy, geo); }));
@@ -758,9 +813,12 @@ int uavtrack_run_greedy(uavtrack_env *env, int32_t T, uint64_t seed, int32_t *ac
     ON_DEVICE(env->cfg.device_id);
     if (env->tpos && T > env->tpos_steps)
         return fail("uavtrack_run_greedy: T = %d exceeds the %d steps the target-trace buffer holds", T, env->tpos_steps);
+    if (env->raw_out && T > env->raw_steps)
+        return fail("uavtrack_run_greedy: T = %d exceeds the %d steps the raw-reward buffer holds", T, env->raw_steps);
     StepParams p = env->base;
     p.T = T;
     p.tpos = env->tpos;
+    p.raw = env->raw_out;
     p.actions = nullptr; p.actions_out = actions_out;
     p.obs = obs; p.reward = reward; p.terms = terms; p.nbrec = nullptr;
     p.covered = covered; p.done = done; p.ep_sums = ep_sums;
@@ -859,6 +917,63 @@ int uavtrack_set_target_trace(uavtrack_env *env, float *tpos, int32_t capacity_s
     if (tpos && capacity_steps < 1) return fail("uavtrack_set_target_trace: capacity_steps must be >= 1 (got %d)", capacity_steps);
     env->tpos = reinterpret_cast<float2 *>(tpos);
     env->tpos_steps = tpos ? capacity_steps : 0;
+    return 0;
+}
+
+int uavtrack_set_raw_reward_output(uavtrack_env *env, float *raw, int32_t capacity_steps)
+{
+    if (!env) return fail("uavtrack_set_raw_reward_output: null handle");
+    if (raw && capacity_steps < 1) return fail("uavtrack_set_raw_reward_output: capacity_steps must be >= 1 (got %d)", capacity_steps);
+    env->raw_out = raw;
+    env->raw_steps = raw ? capacity_steps : 0;
+    return 0;
+}
+
+int uavtrack_step_host(uavtrack_env *env, const int32_t *actions_host, uavtrack_host_step *out, void *stream)
+{
+    if (!env) return fail("uavtrack_step_host: null handle");
+    if (!actions_host || !out) return fail("uavtrack_step_host: actions_host and out must not be null");
+    const uavtrack_config &c = env->cfg;
+    ON_DEVICE(c.device_id);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const HostLayout L = host_layout(c);
+    if (!env->host_blk) {
+        void *h = nullptr, *d = nullptr;
+        HIP_TRY(hipHostMalloc(&h, L.total * 4, hipHostMallocMapped));
+        hipError_t e = hipHostGetDevicePointer(&d, h, 0);
+        if (e != hipSuccess) {
+            (void)hipHostFree(h);
+            return fail("uavtrack_step_host: hipHostGetDevicePointer: %s", hipGetErrorString(e));
+        }
+        memset(h, 0, L.total * 4);
+        env->host_blk = h; env->host_blk_dev = d; env->host_blk_bytes = L.total * 4;
+    }
+    uint32_t *hb = static_cast<uint32_t *>(env->host_blk), *db = static_cast<uint32_t *>(env->host_blk_dev);
+    const size_t BN = (size_t)c.n_envs * c.n_uav;
+    memcpy(hb + L.actions, actions_host, BN * 4);          // the kernel reads them through the mapping: no copy call
+    // the raw rewards are this call's own extra output; a buffer the caller installed comes back afterwards
+    float *const raw_was = env->raw_out;
+    const int32_t raw_steps_was = env->raw_steps;
+    env->raw_out = reinterpret_cast<float *>(db + L.raw); env->raw_steps = 1;
+    const int rc = run_steps(env, 1, reinterpret_cast<const int32_t *>(db + L.actions), reinterpret_cast<float *>(db + L.obs),
+                             reinterpret_cast<float *>(db + L.reward), reinterpret_cast<float *>(db + L.terms),
+                             reinterpret_cast<int32_t *>(db + L.covered), reinterpret_cast<uint8_t *>(db + L.done), nullptr, stream,
+                             "uavtrack_step_host");
+    env->raw_out = raw_was; env->raw_steps = raw_steps_was;
+    if (rc) return rc;
+    const size_t nst = state_slab_floats(c.n_envs, c.n_uav, c.m_targets, c.dim == 3);
+    hipLaunchKernelGGL(state_snapshot_kernel, dim3((unsigned)((nst + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<const uint32_t *>(env->slab), db + L.state, nst);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    const float *hf = reinterpret_cast<const float *>(hb);
+    const StateBlock sv = state_view(const_cast<float *>(hf + L.state), c.n_envs, c.n_uav, c.m_targets, c.dim == 3);
+    out->obs = hf + L.obs; out->reward = hf + L.reward; out->terms = hf + L.terms; out->raw = hf + L.raw;
+    out->covered = reinterpret_cast<const int32_t *>(hb + L.covered);
+    out->done = reinterpret_cast<const uint8_t *>(hb + L.done);
+    out->ux = sv.ux; out->uy = sv.uy; out->uz = sv.uz; out->uh = sv.uh; out->ua = sv.ua;
+    out->tx = sv.tx; out->ty = sv.ty; out->tz = sv.tz; out->th = sv.th;
+    out->step_count = sv.step_count;
     return 0;
 }
 

@@ -14,6 +14,8 @@ namespace uavtrack {
 constexpr float kPi = 3.14159265358979323846f;
 constexpr float kTwoPi = 6.28318530717958647692f;
 constexpr int kMaxWorkgroup = 512;   // __launch_bounds__ of the rollout kernel
+constexpr size_t kLdsSoft = 64 * 1024;    // dynamic LDS a launch gets without asking
+constexpr size_t kLdsMax = 160 * 1024;    // LDS of a gfx950 CU: what one workgroup may take (hipFuncAttributeMaxDynamicSharedMemorySize)
 constexpr int kSymBits = 20;         // fixed-point bits of the shared duplicate term (step_kernel.hip, sym_dup): e * 2^20 < 2^22
 
 // Kernel arguments of one rollout launch (T >= 1 steps).  All pointers are device
@@ -63,6 +65,7 @@ struct StepParams {
     const int32_t *actions;
     float *obs, *reward, *terms;
     float2 *tpos;            // optional target trace [T][B][M] (x, y) after each step (uavtrack_set_target_trace)
+    float *raw;              // optional raw rewards [T][B][N]: uav.raw_reward of environment.py:219 (uavtrack_set_raw_reward_output)
     uint32_t *nbrec;         // MAAC-R: neighbour record per agent-step, read by the deferred softmax mix (nbrec_words())
     int32_t *covered;
     uint8_t *done;
@@ -164,6 +167,12 @@ struct uavtrack_env {
     uint32_t *nbrec = nullptr;
     float2 *tpos = nullptr;           // caller's target-trace buffer (not owned), capacity in steps
     int32_t tpos_steps = 0;
+    float *raw_out = nullptr;         // caller's raw-reward buffer (not owned), capacity in steps (uavtrack_set_raw_reward_output)
+    int32_t raw_steps = 0;
+    // uavtrack_step_host: one pinned, device-mapped host block (actions in, every output and a copy of the state out)
+    void *host_blk = nullptr;         // host address (hipHostMalloc)
+    void *host_blk_dev = nullptr;     // the same block as the device sees it (hipHostGetDevicePointer)
+    size_t host_blk_bytes = 0;
     float *rsum = nullptr;            // [steps][B] per-step mean of the final reward (mix kernel -> episode return)
     // uavtrack_set_profiling: a HIP event pair on the launch stream around every kernel launch of the stepping entry points,
     // by kernel class (UAVTRACK_PROF_*); read and cleared by uavtrack_get_profile
@@ -204,6 +213,7 @@ hipError_t launch_pmi_score(const uavtrack_env *env, const float *obs, hipStream
                             float *scores = nullptr, int n_uav = 0);
 int pmi_effective_scheme(const uavtrack_env *env);              // enum uavtrack_pmi_scheme, never AUTO
 bool pmi_scheme_available(const uavtrack_env *env, int scheme);
+bool pmi_scheme_fits(int hidden_padded, bool f16_range_ok, int scheme);   // the same test for weights that are not loaded yet
 hipError_t launch_pmi_counters_reset(const uavtrack_env *env, hipStream_t stream);
 hipError_t launch_pmi_inference_prep(const float *x, float *obs2, uint2 *pairs, unsigned n, hipStream_t stream);
 hipError_t launch_pmi_finalize(const uavtrack_env *env, int steps, float *reward, float *rsum, hipStream_t stream);

@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(H * 2, 2) pmi_score_kernel(const PmiParams q)
 //     x * w = xh*wh + (xh*wm + xm*wh) + (xh*wl + xl*wh + xm*wm) + O(2^-24 |x w|)
 // -- six bf16 MFMAs (v_mfma_f32_32x32x16_bf16: products exact, fp32 accumulate) replace eight fp32 ones of the same
 // tile at 1/16 the cycles each: 2.67x the fp32 matrix rate, with an error below that of an fp32 fmaf chain
-// (3.7e-6 against 1.1e-5 max over 384-term sums of O(1) data; tools/x6_accuracy.py).  Operands cannot overflow or
+// (3.7e-6 against 1.1e-5 max over 384-term sums of O(1) data; tests/test_host_cpu.py::test_x6_split_error_model_on_adversarial_sums).  Operands cannot overflow or
 // lose range: bf16 has fp32's exponent.
 //
 // Weight-stationary as above, but the three planes of a wavefront's 3H x 32 slice are 2.25 H registers (288 at
@@ -1321,16 +1321,21 @@ int pmi_effective_scheme(const uavtrack_env *env)
     return split && env->pmi.t3 ? UAVTRACK_PMI_F16X3 : split ? UAVTRACK_PMI_BF16X6 : UAVTRACK_PMI_FP32;
 }
 
-bool pmi_scheme_available(const uavtrack_env *env, int scheme)
+bool pmi_scheme_fits(int hidden_padded, bool f16_range_ok, int scheme)
 {
-    const bool split = pmi_x6_floats(env->pmi.hidden) != 0;
+    const bool split = pmi_x6_floats(hidden_padded) != 0;
     switch (scheme) {
     case UAVTRACK_PMI_AUTO:   return true;
-    case UAVTRACK_PMI_F16X3:  return split && env->pmi.t3 != nullptr;     // (null: a weight or an activation bound beyond f16's range)
+    case UAVTRACK_PMI_F16X3:  return split && f16_range_ok;     // (not ok: a weight or an activation bound beyond f16's range)
     case UAVTRACK_PMI_BF16X6: return split;
     case UAVTRACK_PMI_FP32:   return true;
     default:                  return false;
     }
+}
+
+bool pmi_scheme_available(const uavtrack_env *env, int scheme)
+{
+    return pmi_scheme_fits(env->pmi.hidden, env->pmi.t3 != nullptr, scheme);
 }
 
 // One scorer launch over the pair list (the scheme: pmi_effective_scheme).  All three kernels are persistent workgroups

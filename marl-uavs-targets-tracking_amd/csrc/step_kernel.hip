@@ -578,7 +578,7 @@ __device__ __forceinline__ void sweep_weighted(const StepParams &p, int N, int M
 
 // ALLOUT: the caller passed every per-step output (obs, reward, terms, covered, done) -- the rollout a learner
 // consumes and the benchmark workload; the nullable-pointer tests and their SGPR flags then fold away.
-// EXTRAS: the launch uses the rarely wanted per-step extras (target trace, automatic reset); compiled out otherwise --
+// EXTRAS: the launch uses the rarely wanted per-step extras (target trace, raw rewards, automatic reset); compiled out otherwise --
 // their tests and parameters cost the plain rollout ~10 % when they sat in the same instantiation.
 // LONE: built for single-wavefront workgroups on a grid of at most a few waves per SIMD (plan_geometry's small grid).
 template <int N_, int M_, int MODE, bool Z3, int POLICY, bool ALLOUT = false, bool EXTRAS = false, bool LONE = false>
@@ -1167,6 +1167,8 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
                 op[2] = make_float4(o[8], o[9], o[10], o[11]);
             }
             if (p.reward) out_store(at(p.reward + row, lane_off4), r);
+            // optional: uav.raw_reward (environment.py:219), the weighted sum of the three terms before any sharing
+            if (EXTRAS && p.raw) out_store(at(p.raw + row, lane_off4), raw);
             if (p.terms) {                                    // [t][3][b][i]
                 float *tp = p.terms + 3 * row;
                 out_store(at(tp, lane_off4), tt);
@@ -1563,19 +1565,22 @@ Geometry plan_geometry(const uavtrack_config &cfg, int n_simd, bool allow_small_
     static const int kLarge[] = {256, 128, 512, 64};
     static const int kSmall[] = {64, 128, 256, 512};
     // whole environments per workgroup: as many as there are lanes for, fewer when their tables would not fit
-    // the 64 KB of LDS a workgroup may have (few UAVs, many targets: N = 1, M = 70 fits 58 environments, not 64).
+    // the 64 KB of LDS a workgroup has by default (few UAVs, many targets: N = 1, M = 70 fits 58 environments, not 64).
     auto lds_need = [&](int wgs, int E) {
         (void)wgs;
         return lds_bytes_for(E, N, cfg.m_targets, cfg.dim == 3, cfg.reward_mode);
     };
+    // (kLdsSoft = the 64 KiB a launch gets without asking: several environments per workgroup stay inside it, so two or more
+    //  workgroups share a CU; a SINGLE environment whose tables need more -- hundreds of UAVs with thousands of targets --
+    //  may take up to the CU's whole 160 KiB, which launch_rollout requests per kernel, hipFuncSetAttribute)
     auto envs_of = [&](int wgs) {
         int E = wgs / N;
-        while (E > 1 && lds_need(wgs, E) > 64 * 1024) --E;
+        while (E > 1 && lds_need(wgs, E) > kLdsSoft) --E;
         return E;
     };
     auto feasible = [&](int wgs) {
         const int E = envs_of(wgs);
-        return E >= 1 && lds_need(wgs, E) <= 64 * 1024;
+        return E >= 1 && lds_need(wgs, E) <= kLdsMax;
     };
     auto util_of = [&](int wgs) {
         const int E = envs_of(wgs);
@@ -1630,7 +1635,7 @@ hipError_t launch_rollout(uavtrack_env *env, const StepParams &p, hipStream_t st
 {
     int spec = 0;
     const bool allout = p.obs && p.reward && p.terms && p.covered && p.done;
-    const bool extras = p.auto_reset || p.tpos;
+    const bool extras = p.auto_reset || p.tpos || p.raw;
     // MAAC-R: the single-wavefront geometry only pays with the kernel variant written for it (pair-list slots from a pool).
     // Every other launch -- an output not requested, the target trace, the automatic reset -- would run the 4-wave emission
     // path (one pair-list reservation per workgroup-step on ONE counter) on four times the workgroups: measured 15.8
@@ -1644,7 +1649,12 @@ hipError_t launch_rollout(uavtrack_env *env, const StepParams &p, hipStream_t st
     KernelFn fn = pick_kernel(p.N, p.M, env->cfg.reward_mode, env->cfg.dim == 3, &spec, policy, allout, extras, g.lone != 0);
     StepParams q = p;
     q.E = g.envs_per_wg;
-    hipLaunchKernelGGL(fn, dim3(g.groups), dim3(g.wgs), rollout_lds_bytes(g, policy), stream, q);
+    const size_t lds = rollout_lds_bytes(g, policy);
+    if (lds > kLdsSoft) {      // beyond the default limit of a launch: raise this kernel's (a host-side attribute, no stream work)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(fn, dim3(g.groups), dim3(g.wgs), lds, stream, q);
     return hipGetLastError();
 }
 

@@ -35,6 +35,12 @@ class UavtrackConfig(C.Structure):
     ]
 
 
+class HostStep(C.Structure):
+    """Mirror of `struct uavtrack_host_step` (include/uavtrack.h): host pointers into the library's pinned block."""
+    _fields_ = [(k, C.c_void_p) for k in ("obs", "reward", "terms", "raw", "covered", "done",
+                                          "ux", "uy", "uz", "uh", "ua", "tx", "ty", "tz", "th", "step_count")]
+
+
 ACTOR_SAMPLE, ACTOR_ARGMAX = 0, 1   # enum in include/uavtrack.h
 PROF_CLASSES = ("rollout", "scorer", "mix", "ep_sums")   # UAVTRACK_PROF_* in include/uavtrack.h
 PMI_SCHEMES = ("auto", "f16x3", "bf16x6", "fp32")         # enum uavtrack_pmi_scheme
@@ -64,6 +70,8 @@ SIGNATURES = {
     "uavtrack_actor_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "uavtrack_run_actor": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.c_int32] + [C.c_void_p] * 8 + [C.c_void_p]),
     "uavtrack_set_target_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "uavtrack_set_raw_reward_output": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "uavtrack_step_host": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(HostStep), C.c_void_p]),
     "uavtrack_pmi_pairs_scored": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),
     "uavtrack_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "uavtrack_get_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_void_p]),

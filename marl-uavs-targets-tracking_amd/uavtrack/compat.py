@@ -13,11 +13,20 @@ One reference environment is a batch of one on the GPU; every number `step` retu
 from the HIP kernels through the C ABI (uavtrack.BatchedUavEnv).  Batched training should use
 BatchedUavEnv directly.
 
-Identical seeds: the reference draws its reset from Python's global `random` and every target burns one
-unused draw per step (target.py:34).  A batch of one has no use for the device's Philox reset, so this
-adapter draws the reset on the host from the same generator in the same order and consumes the same
-per-step draws: after `random.seed(s)` it starts from the reference's initial state and a caller's own
-`random.randint` actions are the reference's actions, step after step (tests: g1, g6 with no state injection).
+Identical seeds -- for `reset` and for `step` with actions the CALLER supplies: the reference draws its reset
+from Python's global `random` and every target burns one unused draw per step (target.py:34).  A batch of one
+has no use for the device's Philox reset, so this adapter draws the reset on the host from the same generator
+in the same order and consumes the same per-step draws: after `random.seed(s)` it starts from the reference's
+initial state and a caller's own `random.randint` actions are the reference's actions, step after step (tests:
+g1, g6 with no state injection).  The claim does NOT extend to `get_action_by_direction` (C-METHOD): the
+reference's version draws `random.random()` / `np.random.randint` per UAV from the global generators
+(uav.py:340-362) and then calls an undefined `find_closest_a_idx` (uav.py:368); the library's policy draws from
+Philox, keyed by a seed derived from -- but not consuming -- the global generator's state, so a run is
+reproducible under `random.seed` yet not draw-for-draw the reference's.
+
+Speed: one `step` is ONE library call (uavtrack_step_host): the kernels write the results and the state into
+a page-locked host block, the call returns after one stream synchronisation, and everything this class hands
+out is read from numpy views of that block -- no per-step device allocation, no device-to-host copy calls.
 """
 from __future__ import annotations
 
@@ -42,9 +51,11 @@ def reference_reset_draw(config, n_uav: int, m_targets: int, x_max: float, y_max
     e = config['environment']
     pi = math.pi
     n_cfg = int(e['n_uav'])
-    if n_cfg != n_uav:        # the reference would raise IndexError (fewer) or leave UAVs out (more)
-        raise ValueError(f"config['environment']['n_uav'] = {n_cfg} != the environment's {n_uav}")
-    init_x = [x * e['x_max'] / (n_cfg + 1) for x in range(1, n_cfg + 1)]
+    if n_cfg < n_uav:         # the reference raises IndexError here (init_x[i] past the list, environment.py:59)
+        raise ValueError(f"config['environment']['n_uav'] = {n_cfg} < the environment's {n_uav}")
+    # (more UAVs in the config than in the environment: the reference lays out n_cfg positions, spaced by
+    #  x_max / (n_cfg + 1), and uses the first n_uav of them -- environment.py:54-59, 105)
+    init_x = [x * e['x_max'] / (n_cfg + 1) for x in range(1, n_cfg + 1)][:n_uav]
     init_y = e['y_max'] / 2
     uh, ua = [], []
     for _ in range(n_uav):
@@ -70,6 +81,15 @@ def reference_step_draws(config, m_targets: int) -> None:
         random.uniform(-h_max_t, h_max_t)
 
 
+def seed_from_global_random() -> int:
+    """A 63-bit seed pinned by `random.seed(...)` that does NOT advance the global generator: drawn from a copy of its
+    state.  (hash(random.getstate()) would not do: the state tuple ends in None, whose hash is an address on CPython
+    3.10 and changes from process to process.)"""
+    r = random.Random()
+    r.setstate(random.getstate())
+    return r.getrandbits(63)
+
+
 class _UavView:
     """What the callers touch on `env.uav_list[i]` (uav.py:12-51 attributes, :192)."""
 
@@ -86,13 +106,16 @@ class _UavView:
         compatibility -- the policy works on the environment's own state."""
         return self._env._greedy_action(self._i)
 
-    x = property(lambda self: float(self._env._host_state()["ux"][self._i]))
-    y = property(lambda self: float(self._env._host_state()["uy"][self._i]))
-    h = property(lambda self: float(self._env._host_state()["uh"][self._i]))
-    a = property(lambda self: int(self._env._host_state()["ua"][self._i]))
+    x = property(lambda self: float(self._env._state["ux"][self._i]))
+    y = property(lambda self: float(self._env._state["uy"][self._i]))
+    h = property(lambda self: float(self._env._state["uh"][self._i]))
+    a = property(lambda self: int(self._env._state["ua"][self._i]))
     dp = property(lambda self: self._env._cfg.dp)
     dc = property(lambda self: self._env._cfg.dc)
-    raw_reward = property(lambda self: None)
+    # uav.raw_reward (uav.py:50, set at environment.py:219) and uav.reward (environment.py:226) of the last step.
+    # (The per-UAV observation LISTS, uav.target_observation / uav.uav_communication, are scratch of the reference's
+    #  get_local_state and are not materialised: the kernel folds them into the 12-d local state.)
+    raw_reward = property(lambda self: float(self._env._last_raw[self._i]))
     reward = property(lambda self: float(self._env._last_reward[self._i]))
 
 
@@ -100,9 +123,9 @@ class _TargetView:
     def __init__(self, env: "Environment", k: int):
         self._env, self._k = env, k
 
-    x = property(lambda self: float(self._env._host_state()["tx"][self._k]))
-    y = property(lambda self: float(self._env._host_state()["ty"][self._k]))
-    h = property(lambda self: float(self._env._host_state()["th"][self._k]))
+    x = property(lambda self: float(self._env._state["tx"][self._k]))
+    y = property(lambda self: float(self._env._state["ty"][self._k]))
+    h = property(lambda self: float(self._env._state["th"][self._k]))
 
 
 class Environment:
@@ -121,7 +144,9 @@ class Environment:
         self._cfg: Optional[EnvConfig] = None
         self._obs = np.zeros((n_uav, 12), dtype=np.float64)
         self._last_reward = np.zeros(n_uav)
-        self._state_cache = None
+        self._last_raw = np.zeros(n_uav)
+        self._state = None                          # ux uy uh ua tx ty th of the one environment (numpy, fp32 / int32)
+        self._act = np.zeros((1, n_uav), dtype=np.int32)
         self._pmi_id = None
         self._episode = 0
         self._greedy_cache = None
@@ -135,8 +160,8 @@ class Environment:
 
     def _make(self, config, mode: RewardMode):
         cfg = EnvConfig.from_reference_dict(config, n_envs=1, reward_mode=mode, horizon=0)
-        # the env object's own sizes rule the simulation; config's n_uav/m_targets only
-        # enter the reward normalisation (environment.py:208-210)
+        # the env object's own sizes rule the simulation; config's n_uav/m_targets only enter the reward normalisation
+        # (environment.py:208-210) and, at reset, the spacing of the UAVs' start positions (environment.py:105)
         cfg = cfg.with_(n_uav=self.n_uav, m_targets=self.m_targets, x_max=float(self.x_max),
                         y_max=float(self.y_max), na=int(self.action_dim),
                         norm_n_uav=int(config['environment']['n_uav']),
@@ -144,6 +169,13 @@ class Environment:
         return cfg
 
     def _ensure(self, config, mode: RewardMode):
+        # (every value the reference reads from `config` per step or per reset, as one tuple: the dict -> EnvConfig
+        #  conversion and the handle survive for as long as the caller leaves them alone)
+        e, u = config['environment'], config['uav']
+        key = (mode, e['n_uav'], e['m_targets'], e['x_max'], e['y_max'], e['na'], u['dt'], u['v_max'], u['h_max'], u['dc'],
+               u['dp'], u['alpha'], u['beta'], u['gamma'], config['target']['v_max'], config.get('cooperative', 0))
+        if self._env is not None and key == getattr(self, "_cfg_key", None):
+            return
         cfg = self._make(config, mode)
         if self._env is None or cfg != self._cfg:
             state = self._env.get_state() if self._env is not None else None
@@ -154,12 +186,11 @@ class Environment:
             self._pmi_id = None
             if state is not None:
                 self._env.set_state(**state)
+        self._cfg_key = key
 
     def _host_state(self):
-        if self._state_cache is None:
-            s = self._env.get_state()
-            self._state_cache = {k: v[0].cpu().numpy() for k, v in s.items() if k != "step_count"}
-        return self._state_cache
+        """ux uy uh ua tx ty th of the environment as numpy arrays (kept for callers of earlier versions)."""
+        return self._state
 
     # -- reference surface ------------------------------------------------------------
     def reset(self, config):
@@ -182,7 +213,10 @@ class Environment:
         obs[:, 10] = st0["uy"] / dc
         obs[:, 11] = np.asarray(ua, np.float64) / float(self.action_dim)
         self._obs = obs
-        self._state_cache = None
+        # the state as the library holds it: fp32 poses, int32 actions
+        self._state = {k: (np.asarray(v, np.int32) if k == "ua" else np.asarray(v, np.float32)) for k, v in st0.items()}
+        self._last_reward = np.zeros(self.n_uav)
+        self._last_raw = np.zeros(self.n_uav)
         self.uav_list = [_UavView(self, i) for i in range(self.n_uav)]
         self.target_list = [_TargetView(self, k) for k in range(self.m_targets)]
         self.position = {'all_uav_xs': [], 'all_uav_ys': [], 'all_target_xs': [], 'all_target_ys': []}
@@ -190,7 +224,7 @@ class Environment:
         self._greedy_cache = None
 
     def get_states(self) -> List[np.ndarray]:
-        return [self._obs[i].copy() for i in range(self.n_uav)]   # environment.py:109-118
+        return list(self._obs.copy())                # environment.py:109-118: one 12-vector per UAV
 
     def _greedy_action(self, i: int) -> int:
         step = len(self.covered_target_num)
@@ -198,26 +232,28 @@ class Environment:
             if self._greedy_seed is None:
                 # pinned by random.seed like everything else, without consuming a draw (the library's policy draws are
                 # Philox: the global generator stays where the environment's own draws leave it)
-                self._greedy_seed = hash(random.getstate()) & (2 ** 63 - 1)
+                self._greedy_seed = seed_from_global_random()
             acts = self._env.greedy_actions(seed=self._greedy_seed)[0].cpu().numpy()
             self._greedy_cache = ((self._episode, step), acts)
         return int(self._greedy_cache[1][i])
 
     def step(self, config, pmi, actions):
+        """environment.py:120-164: (next_states, reward dict, covered targets).  One library call, one synchronisation."""
         mode = self._mode_for(config, pmi)
         self._ensure(config, mode)
         if mode == RewardMode.PMI and (id(pmi) != self._pmi_id or not self.covered_target_num):
             self._env.set_pmi(pmi.state_dict())   # weights change between episodes (train.py:262)
             self._pmi_id = id(pmi)
         reference_step_draws(config, self.m_targets)           # target.py:34
-        a = torch.as_tensor(np.asarray(actions, dtype=np.int32).reshape(1, self.n_uav))
-        obs, reward, _ = self._env.step(a)
-        terms = self._env.info["terms"][:, 0].double().cpu().numpy()
-        covered = int(self._env.info["covered"][0].item())
-        self._obs = obs[0].double().cpu().numpy()
-        self._last_reward = reward[0].double().cpu().numpy()
-        self._state_cache = None
-        st = self._host_state()
+        self._act[0, :] = actions
+        v = self._env.step_host(self._act)                     # numpy views of the library's host block
+        covered = int(v["covered"][0])
+        self._obs = v["obs"][0].astype(np.float64)
+        self._last_reward = v["reward"][0].astype(np.float64)
+        self._last_raw = v["raw"][0].astype(np.float64)
+        terms = v["terms"][:, 0].astype(np.float64)
+        self._state = {k: v[k][0].copy() for k in ("ux", "uy", "uh", "ua", "tx", "ty", "th")}
+        st = self._state
         self.covered_target_num.append(covered)                      # environment.py:147
         self.position['all_target_xs'].append(st["tx"].tolist())     # environment.py:150-155
         self.position['all_target_ys'].append(st["ty"].tolist())

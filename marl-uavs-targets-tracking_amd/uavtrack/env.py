@@ -44,6 +44,9 @@ class BatchedUavEnv:
         self.info: Dict[str, torch.Tensor] = {}
         self._episode = 0
         self._trace: Optional[torch.Tensor] = None    # the installed target-trace buffer (kept alive: the library holds its raw pointer)
+        self._raw: Optional[torch.Tensor] = None      # ... and the raw-reward buffer (set_raw_output)
+        self._host_step = _lib.HostStep()             # step_host: the library's host result block and numpy views of it
+        self._host_views: Optional[Dict[str, np.ndarray]] = None
 
     # -- plumbing ---------------------------------------------------------------------
     @property
@@ -142,6 +145,8 @@ class BatchedUavEnv:
             _lib.check(self._lib.uavtrack_step(self._h, _ptr(a), _ptr(obs), _ptr(reward), _ptr(terms),
                                                _ptr(covered), _ptr(done), self._stream()), "uavtrack_step")
         self.info = {"terms": terms, "covered": covered}
+        if self._raw is not None:
+            self.info["raw"] = self._raw[0]       # uav.raw_reward of this step (set_raw_output)
         return obs, reward, done.bool()
 
     def set_target_trace(self, buf: Optional[torch.Tensor]) -> None:
@@ -155,6 +160,58 @@ class BatchedUavEnv:
             raise ValueError(f"target trace must be a contiguous float32 [T, {self.B}, {self.M}, 2] tensor on {self.device}")
         _lib.check(self._lib.uavtrack_set_target_trace(self._h, _ptr(buf), C.c_int32(buf.shape[0])), "uavtrack_set_target_trace")
         self._trace = buf     # every later launch writes through the raw pointer: the tensor must outlive them
+
+    def set_raw_output(self, buf: Optional[torch.Tensor]) -> None:
+        """uav.raw_reward of every UAV after each step, [T, B, N] (environment.py:219: the weighted sum of the three
+        normalised terms before any cooperative sharing), written by every later stepping call until replaced; None
+        switches the output off."""
+        if buf is None:
+            _lib.check(self._lib.uavtrack_set_raw_reward_output(self._h, None, 0), "uavtrack_set_raw_reward_output")
+            self._raw = None
+            return
+        if buf.dim() != 3 or not self._fits(buf, (buf.shape[0], self.B, self.N), torch.float32):
+            raise ValueError(f"raw-reward buffer must be a contiguous float32 [T, {self.B}, {self.N}] tensor on {self.device}")
+        _lib.check(self._lib.uavtrack_set_raw_reward_output(self._h, _ptr(buf), C.c_int32(buf.shape[0])),
+                   "uavtrack_set_raw_reward_output")
+        self._raw = buf       # (kept alive: the library holds its raw pointer)
+
+    def _with_raw(self, T: int, want: bool, o, launch):
+        """Run `launch()` with a [T, B, N] raw-reward buffer attached when asked; returns it (or None)."""
+        if not want:
+            return launch(), None
+        rb = self._reuse(o, "raw", (T, self.B, self.N), torch.float32)
+        installed = self._raw
+        self.set_raw_output(rb)
+        try:
+            return launch(), rb
+        finally:
+            self.set_raw_output(installed)
+
+    def step_host(self, actions: np.ndarray) -> Dict[str, np.ndarray]:
+        """Environment.step for a host caller (uavtrack_step_host): `actions` is a C-contiguous int32 numpy array [B, N];
+        returns numpy VIEWS of the library's page-locked result block -- obs [B, N, 12], reward [B, N], terms [3, B, N],
+        raw [B, N], covered [B], done [B] and the state behind the step (ux uy uh ua tx ty th [uz tz] step_count) -- valid
+        until the next step_host on this environment.  Synchronises the stream."""
+        if actions.dtype != np.int32 or not actions.flags.c_contiguous or actions.size != self.B * self.N:
+            raise ValueError(f"actions must be a C-contiguous int32 array of {self.B} x {self.N} entries")
+        hs = self._host_step
+        ptrs = tuple(getattr(hs, k) for k, _ in _lib.HostStep._fields_) if self._host_views is not None else None
+        _lib.check(self._lib.uavtrack_step_host(self._h, C.c_void_p(actions.ctypes.data), C.byref(hs), self._stream()),
+                   "uavtrack_step_host")
+        if self._host_views is None or ptrs != tuple(getattr(hs, k) for k, _ in _lib.HostStep._fields_):
+            B, N, M = self.B, self.N, self.M
+
+            def view(ptr, shape, ctype, dtype):
+                if not ptr:
+                    return None
+                n = int(np.prod(shape))
+                return np.frombuffer((ctype * n).from_address(ptr), dtype=dtype).reshape(shape)
+            f, i32, u8 = (C.c_float, np.float32), (C.c_int32, np.int32), (C.c_uint8, np.uint8)
+            spec = dict(obs=((B, N, _lib.OBS_DIM), f), reward=((B, N), f), terms=((3, B, N), f), raw=((B, N), f),
+                        covered=((B,), i32), done=((B,), u8), ux=((B, N), f), uy=((B, N), f), uz=((B, N), f), uh=((B, N), f),
+                        ua=((B, N), i32), tx=((B, M), f), ty=((B, M), f), tz=((B, M), f), th=((B, M), f), step_count=((B,), i32))
+            self._host_views = {k: view(getattr(hs, k), shape, ct, dt) for k, (shape, (ct, dt)) in spec.items()}
+        return self._host_views
 
     def _with_targets(self, T: int, want: bool, o, launch):
         """Run `launch()` with a [T, B, M, 2] target trace attached when asked; returns the trace (or None)."""
@@ -172,9 +229,10 @@ class BatchedUavEnv:
 
     def step_many(self, actions, want_obs: bool = True, want_terms: bool = True, want_ep_sums: bool = True,
                   out: Optional[Dict[str, torch.Tensor]] = None, want_targets: bool = False,
-                  auto_reset_seed: Optional[int] = None) -> Dict[str, torch.Tensor]:
+                  auto_reset_seed: Optional[int] = None, want_raw: bool = False) -> Dict[str, torch.Tensor]:
         """T steps in one launch; `actions` is [T, B, N].  Pass the previous result as
-        `out` to reuse its buffers.  want_targets adds "targets" [T, B, M, 2], the target tracks of t_xy<ep>.csv.
+        `out` to reuse its buffers.  want_targets adds "targets" [T, B, M, 2], the target tracks of t_xy<ep>.csv;
+        want_raw adds "raw" [T, B, N], uav.raw_reward (environment.py:219).
         auto_reset_seed: environments whose done flag fires are reset inside the launch (reset(seed, next episode)),
         so the launch may span episodes (uavtrack_step_many_autoreset)."""
         a = torch.as_tensor(actions)
@@ -200,12 +258,14 @@ class BatchedUavEnv:
                 self._lib.uavtrack_step_many_autoreset(self._h, C.c_int32(T), C.c_uint64(auto_reset_seed & (2 ** 64 - 1)), _ptr(a),
                                                        _ptr(obs), _ptr(reward), _ptr(terms), _ptr(covered), _ptr(done), _ptr(ep),
                                                        self._stream()), "uavtrack_step_many_autoreset")
-        tp = self._with_targets(T, want_targets, o, launch)
+        tp, rb = self._with_raw(T, want_raw, o, lambda: self._with_targets(T, want_targets, o, launch))
         if auto_reset_seed is not None and self.cfg.horizon > 0:
             self._episode += T // self.cfg.horizon + 1      # stay ahead of the episode numbers the device has used
         res = dict(obs=obs, reward=reward, terms=terms, covered=covered, done=done, ep_sums=ep)
         if tp is not None:
             res["targets"] = tp
+        if rb is not None:
+            res["raw"] = rb          # uav.raw_reward per step (environment.py:219)
         return res
 
     def bind_step_many(self, actions: torch.Tensor, out: Dict[str, torch.Tensor]):

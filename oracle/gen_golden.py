@@ -18,6 +18,7 @@ Scenarios:
   g5b N50 M25  coop .3  PMI      4 seeds x 25 steps
   g6  reset-only layouts N in {5,10,20,50}
   g7  hand-placed edge cases (walls, wraps, inclusive/strict thresholds, ...)
+  g9  range tests one fp32 ulp inside / outside their thresholds after the move
   g8  non-default constants (dt .5, v_max 13, h_max pi/5, dp 173.3, dc 411.7, alpha/beta/gamma .5/.3/.2, target v_max 7,
       na 9, 1500 x 1100 box, reward normalisation by config n_uav / m_targets != the environment's own): N20 M10 MAAC-G
       and MAAC-R H64, N7 M4 MAAC; 4 seeds x 25 steps each
@@ -218,6 +219,10 @@ def gen_edges(pmi):
                 for _ in range(m)],
         actions=[[int(a) for a in rng.randint(0, 12, size=n)] for _ in range(3)], coop=0.3, use_pmi=True)
 
+    run_cases("g7_edges", cases, pmi)
+
+
+def run_cases(name, cases, pmi):
     arrays, meta = {}, {"cases": []}
     for c in cases:
         n, m = len(c["uav"]), len(c["target"])
@@ -228,7 +233,37 @@ def gen_edges(pmi):
             arrays[f"{c['name']}__{k}"] = v
         meta["cases"].append(dict(name=c["name"], n_uav=n, m_targets=m, cooperative=c["coop"],
                                   pmi=c["use_pmi"], steps=len(c["actions"])))
-    save("g7_edges", arrays, meta)
+    save(name, arrays, meta)
+
+
+def gen_ulp_edges():
+    """g9: range tests ONE fp32 ULP either side of their threshold AFTER the move (g7's threshold cases sit exactly on
+    the thresholds, all representable).  Everything flies along y = 1000 with heading 0, so a move adds exactly 20 m
+    (UAV) / 5 m (target) to x and nothing to y: the post-move coordinates are fp32 numbers in the reference's fp64
+    arithmetic and in the kernel's fp32 alike, and so are their differences -- the only thing under test is the
+    comparison itself.  UAV 0 ends at x = 56.  `inside`: target 0 ends one ulp(256) short of 256 (d = dp - 2^-16:
+    observed, tracked AND covered), UAV 1 one ulp(512) short of 556 (d = dc - 2^-14: communicates), UAV 2 one ulp(256)
+    short of 456 (d = 2 dp - 2^-15: duplicate punishment), UAV 3 one ulp short of 256 at y = 1000 (d = dp - 2^-16 to UAV 0:
+    a cooperative neighbour).  `outside`: the same four one ulp beyond.  MAAC-G so that the neighbour test shows."""
+    u = lambda e: 2.0 ** e                     # noqa: E731
+    cases = []
+    for name, sgn in (("ulp_inside", -1.0), ("ulp_outside", +1.0)):
+        # (below a power of two the spacing halves: one ulp short of 256 is 256 - 2^-16, one ulp beyond is 256 + 2^-15)
+        t0 = 256.0 + (sgn * u(-16) if sgn < 0 else u(-15))
+        u1 = 556.0 + sgn * u(-14)
+        u2 = 456.0 + sgn * u(-15)
+        u3 = 256.0 + (sgn * u(-16) if sgn < 0 else u(-15))
+        cases.append(dict(name=name,
+                          uav=[(56.0 - 20.0, 1000.0, 0.0, 3), (u1 - 20.0, 1000.0, 0.0, 7), (u2 - 20.0, 1000.0, 0.0, 1),
+                               (u3 - 20.0, 1000.0, 0.0, 9)],
+                          target=[(t0 - 5.0, 1000.0, 0.0), (1500.0, 300.0, 0.0)],
+                          actions=[[5, 6, 2, 9]], coop=0.3, use_pmi=False))
+    for c in cases:       # every coordinate must be an fp32 number before and after the move
+        for (x, y, h, a), v in zip(c["uav"], [20.0] * 4):
+            assert float(np.float32(x)) == x and float(np.float32(x + v)) == x + v, (c["name"], x)
+        assert float(np.float32(c["target"][0][0])) == c["target"][0][0]
+        assert float(np.float32(c["target"][0][0] + 5.0)) == c["target"][0][0] + 5.0
+    run_cases("g9_ulp_edges", cases, None)
 
 
 def gen_actor():
@@ -392,6 +427,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--only-greedy":
         gen_greedy()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-ulp":
+        gen_ulp_edges()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--only-h64":
         gen_h64()
         return
@@ -414,6 +452,7 @@ def main():
     gen_nondefault()
     gen_pmi_train()
     gen_export()
+    gen_ulp_edges()
 
 
 if __name__ == "__main__":

@@ -66,6 +66,7 @@ def lib():
         build()
         _lib = C.CDLL(_LIB_PATH)
         _lib.orc_step.restype = C.c_int
+        _lib.orc_step_rows.restype = C.c_int
         _lib.orc_reset_obs.restype = C.c_int
         _lib.orc_reset_philox.restype = C.c_int
         _lib.orc_philox4x32_10.restype = None
@@ -205,22 +206,24 @@ class OracleEnv:
         return obs
 
     def step(self, actions):
-        """-> dict(obs[B,N,12], reward[B,N], terms[3,B,N], raw[B,N], covered[B], margin[B])."""
+        """-> dict(obs[B,N,12], reward[B,N], terms[3,B,N], raw[B,N], covered[B], margin[B], margin_row[B,N]).
+        margin: min |d - threshold| over every range / wall test of the environment this step; margin_row: over the tests
+        that can change that UAV's own observation row, terms and raw reward (uav_oracle.h, orc_step_rows)."""
         B, N = self.cfg.n_envs, self.cfg.n_uav
         act = np.ascontiguousarray(np.asarray(actions, dtype=np.int32).reshape(B * N))
         obs = np.empty((B, N, 12)); reward = np.empty((B, N)); terms = np.empty((3, B, N))
-        raw = np.empty((B, N)); covered = np.empty(B, dtype=np.int32); margin = np.empty(B)
+        raw = np.empty((B, N)); covered = np.empty(B, dtype=np.int32); margin = np.empty(B); margin_row = np.empty((B, N))
         c = self.cfg.c_struct()
         pm = self.pmi.c_struct() if self.pmi is not None else None
-        rc = lib().orc_step(C.byref(c),
+        rc = lib().orc_step_rows(C.byref(c),
                             _dp(self.ux), _dp(self.uy), _dp(self.uz), _dp(self.uh), _ip(self.ua),
                             _dp(self.tx), _dp(self.ty), _dp(self.tz), _dp(self.th),
                             _ip(act), C.byref(pm) if pm is not None else None,
-                            _dp(obs), _dp(reward), _dp(terms), _dp(raw), _ip(covered), _dp(margin),
+                            _dp(obs), _dp(reward), _dp(terms), _dp(raw), _ip(covered), _dp(margin), _dp(margin_row),
                             C.c_int(self.n_threads))
         if rc != 0:
             raise RuntimeError(f"orc_step failed: {rc}")
-        return dict(obs=obs, reward=reward, terms=terms, raw=raw, covered=covered, margin=margin)
+        return dict(obs=obs, reward=reward, terms=terms, raw=raw, covered=covered, margin=margin, margin_row=margin_row)
 
 
 def greedy_actions(env: "OracleEnv", seed: int, step_count, env_offset: int = 0, force_argmax: bool = False):

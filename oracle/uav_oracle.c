@@ -111,6 +111,7 @@ typedef struct {
     double *local;   /* [N][12] get_local_state             (uav.py:156-190) */
     double *rawr;    /* [N] uav.raw_reward */
     double *pmi_scratch;
+    double *twall;   /* [M] test aid: each target's distance to the nearest wall test of its move */
 } env_scratch;
 
 static void step_one_env(const orc_config *c, const orc_pmi *pmi, env_scratch *s,
@@ -118,7 +119,7 @@ static void step_one_env(const orc_config *c, const orc_pmi *pmi, env_scratch *s
                          double *tx, double *ty, double *tz, double *th,
                          const int32_t *act,
                          double *obs, double *reward, double *tt, double *bp, double *dup,
-                         double *raw, int32_t *covered, double *margin)
+                         double *raw, int32_t *covered, double *margin, double *margin_row)
 {
     const int N = c->n_uav, M = c->m_targets;
     const int three_d = (c->dim == 3);
@@ -135,6 +136,11 @@ static void step_one_env(const orc_config *c, const orc_pmi *pmi, env_scratch *s
         note_margin(&mg, ty[k], c->y_max);
         note_margin(&mg, tx[k], 0.0);
         note_margin(&mg, tx[k], c->x_max);
+        s->twall[k] = INFINITY;
+        note_margin(&s->twall[k], ty[k], 0.0);
+        note_margin(&s->twall[k], ty[k], c->y_max);
+        note_margin(&s->twall[k], tx[k], 0.0);
+        note_margin(&s->twall[k], tx[k], c->x_max);
         if (0.0 > ty[k] || ty[k] > c->y_max) {          /* target.py:52-53 */
             th[k] = -th[k];
         } else if (tx[k] < 0.0 || tx[k] > c->x_max) {   /* target.py:54-58 */
@@ -162,6 +168,12 @@ static void step_one_env(const orc_config *c, const orc_pmi *pmi, env_scratch *s
         if (three_d) uz[i] += c->dt * c->u_v_max * sg;
         uh[i] += c->dt * w;
         uh[i] = py_fmod_pos(uh[i] + ORC_PI, 2.0 * ORC_PI) - ORC_PI;
+        /* margin_row[i] (test aid): the knife edges that can change THIS UAV's observation row, its three reward terms
+         * and its raw reward -- its own range tests against targets (dp) and peers (dc on the sequential view, 2 dp on
+         * the post-move poses) and the wall tests of the targets it observes or nearly observes (a mirrored heading
+         * enters the row, uav.py:116-117).  The neighbour test of the cooperative reward and the strict coverage test
+         * couple UAVs of the environment and stay in the per-environment margin only. */
+        if (margin_row) margin_row[i] = INFINITY;
 
         /* UAV.observe_target, uav.py:101-122 (relative=True) */
         s->cnt_t[i] = 0;
@@ -169,6 +181,10 @@ static void step_one_env(const orc_config *c, const orc_pmi *pmi, env_scratch *s
             double d = three_d ? dist3(ux[i], uy[i], uz[i], tx[k], ty[k], tz[k])
                                : dist2(ux[i], uy[i], tx[k], ty[k]);
             note_margin(&mg, d, c->dp);
+            if (margin_row) {
+                note_margin(&margin_row[i], d, c->dp);
+                if (d <= c->dp + 1.0 && s->twall[k] < margin_row[i]) margin_row[i] = s->twall[k];
+            }
             if (d <= c->dp) {
                 double *row = s->obs_t + ((size_t)i * M + s->cnt_t[i]) * 4;
                 row[0] = (tx[k] - ux[i]) / c->dp;
@@ -186,6 +202,7 @@ static void step_one_env(const orc_config *c, const orc_pmi *pmi, env_scratch *s
             d = three_d ? dist3(ux[i], uy[i], uz[i], ux[j], uy[j], uz[j])
                         : dist2(ux[i], uy[i], ux[j], uy[j]);
             note_margin(&mg, d, c->dc);
+            if (margin_row) note_margin(&margin_row[i], d, c->dc);
             if (d <= c->dc) {
                 double *row = s->obs_u + ((size_t)i * N + s->cnt_u[i]) * 5;
                 row[0] = (ux[j] - ux[i]) / c->dc;
@@ -257,6 +274,7 @@ static void step_one_env(const orc_config *c, const orc_pmi *pmi, env_scratch *s
             d = three_d ? dist3(ux[i], uy[i], uz[i], ux[j], uy[j], uz[j])
                         : dist2(ux[i], uy[i], ux[j], uy[j]);
             note_margin(&mg, d, 2.0 * c->dp);
+            if (margin_row) note_margin(&margin_row[i], d, 2.0 * c->dp);
             note_margin(&mg, d, c->dp);   /* neighbour test of the cooperative reward */
             if (d <= 2.0 * c->dp)
                 punish += -0.5 * exp((2.0 * c->dp - d) / (2.0 * c->dp));
@@ -345,21 +363,22 @@ static int scratch_alloc(env_scratch *s, int N, int M, int H)
     s->local = (double *)malloc(sizeof(double) * 12 * (size_t)N);
     s->rawr  = (double *)malloc(sizeof(double) * N);
     s->pmi_scratch = (double *)malloc(sizeof(double) * 4 * (size_t)(H > 0 ? H : 1));
-    return (s->obs_t && s->cnt_t && s->obs_u && s->cnt_u && s->local && s->rawr && s->pmi_scratch) ? 0 : -1;
+    s->twall = (double *)malloc(sizeof(double) * (size_t)(M > 0 ? M : 1));
+    return (s->obs_t && s->cnt_t && s->obs_u && s->cnt_u && s->local && s->rawr && s->pmi_scratch && s->twall) ? 0 : -1;
 }
 
 static void scratch_free(env_scratch *s)
 {
     free(s->obs_t); free(s->cnt_t); free(s->obs_u); free(s->cnt_u);
-    free(s->local); free(s->rawr); free(s->pmi_scratch);
+    free(s->local); free(s->rawr); free(s->pmi_scratch); free(s->twall);
 }
 
-int orc_step(const orc_config *cfg,
-             double *ux, double *uy, double *uz, double *uh, int32_t *ua,
-             double *tx, double *ty, double *tz, double *th,
-             const int32_t *actions, const orc_pmi *pmi,
-             double *obs, double *reward, double *terms, double *raw,
-             int32_t *covered, double *margin, int n_threads)
+int orc_step_rows(const orc_config *cfg,
+                  double *ux, double *uy, double *uz, double *uh, int32_t *ua,
+                  double *tx, double *ty, double *tz, double *th,
+                  const int32_t *actions, const orc_pmi *pmi,
+                  double *obs, double *reward, double *terms, double *raw,
+                  int32_t *covered, double *margin, double *margin_row, int n_threads)
 {
     const int B = cfg->n_envs, N = cfg->n_uav, M = cfg->m_targets;
     const size_t BN = (size_t)B * N;
@@ -397,11 +416,23 @@ int orc_step(const orc_config *cfg,
                          terms ? terms + 2 * BN + un : NULL,
                          raw ? raw + un : NULL,
                          covered ? covered + b : NULL,
-                         margin ? margin + b : NULL);
+                         margin ? margin + b : NULL,
+                         margin_row ? margin_row + un : NULL);
         }
         scratch_free(&s);
     }
     return fail ? -3 : 0;
+}
+
+int orc_step(const orc_config *cfg,
+             double *ux, double *uy, double *uz, double *uh, int32_t *ua,
+             double *tx, double *ty, double *tz, double *th,
+             const int32_t *actions, const orc_pmi *pmi,
+             double *obs, double *reward, double *terms, double *raw,
+             int32_t *covered, double *margin, int n_threads)
+{
+    return orc_step_rows(cfg, ux, uy, uz, uh, ua, tx, ty, tz, th, actions, pmi, obs, reward, terms, raw, covered, margin, NULL,
+                         n_threads);
 }
 
 int orc_reset_obs(const orc_config *cfg, const double *ux, const double *uy,

@@ -310,8 +310,39 @@ def test_reference_reset_and_step_draws_are_seed_identical():
         a = [random.randint(0, 11) for _ in range(5)]
         assert a == [int(v) for v in z1["actions"][0, t]], t
         reference_step_draws(cfg, 3)
+    # a config with FEWER UAVs than the environment: the reference raises IndexError (environment.py:59) -- refused here too
     with pytest.raises(ValueError):
-        reference_reset_draw(_ref_cfg(6, 3), 5, 3, 2000, 2000, 12)
+        reference_reset_draw(_ref_cfg(4, 3), 5, 3, 2000, 2000, 12)
+    # ... with MORE: the reference lays out n_cfg start positions, spaced by x_max / (n_cfg + 1), and uses the first n_uav
+    # (environment.py:54-59, 105).  Expected values: the unmodified reference, Environment(n_uav=5) reset with a config
+    # that says n_uav = 6, after random.seed(42)
+    random.seed(42)
+    st = reference_reset_draw(_ref_cfg(6, 3), 5, 3, 2000, 2000, 12)
+    np.testing.assert_array_equal(st["ux"], [i * 2000 / 7 for i in range(1, 6)])
+    np.testing.assert_allclose(st["uh"][:2], [0.8760444114976647, 1.5177065510328678], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(st["tx"], [1180.9850248980792, 1204.0374580999608, 839.0396419233175], rtol=0, atol=1e-12)
+
+
+def test_greedy_seed_is_pinned_by_random_seed_across_processes():
+    """The C-METHOD path of the adapter keys the library's Philox draws with a seed derived from the global generator's
+    state (compat.seed_from_global_random).  It must be the same in every process after the same random.seed -- a hash of
+    the state tuple is not (it ends in None, whose hash is an address on CPython 3.10) -- and must not consume a draw."""
+    import random
+    import subprocess
+    import sys
+    from uavtrack.compat import seed_from_global_random
+    code = ("import sys; sys.path[:0] = %r; import random; from uavtrack.compat import seed_from_global_random; "
+            "random.seed(42); print(seed_from_global_random())" % ([ROOT, os.path.join(ROOT, "marl-uavs-targets-tracking_amd")],))
+    outs = [subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.strip() for _ in range(2)]
+    random.seed(42)
+    here = seed_from_global_random()
+    assert outs[0] == outs[1] == str(here), (outs, here)
+    assert 0 <= here < 2 ** 63
+    nxt = random.random()
+    random.seed(42)
+    assert random.random() == nxt          # the derivation left the generator where random.seed put it
+    random.seed(43)
+    assert seed_from_global_random() != here
 
 
 def build_abi_client(tmp_path):

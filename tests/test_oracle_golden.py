@@ -107,6 +107,37 @@ def test_edge_cases(pmi_state_dict):
         check_episode(z, case["name"] + "__", None, case, pmi_state_dict, case["steps"])
 
 
+def test_ulp_edge_cases_and_row_margins():
+    """g9: range tests one fp32 ulp inside / outside dp, dc and 2 dp after the move (recorded from the reference), and
+    the oracle's per-row margins on them: the UAVs that hold such a test report a margin of one ulp, the others do not."""
+    z, meta = load_golden("g9_ulp_edges")
+    for case in meta["cases"]:
+        check_episode(z, case["name"] + "__", None, case, None, case["steps"])
+    # what the goldens exercise: inside, UAV 0 observes and tracks target 0 (d = dp - 2^-16); outside it does not
+    assert 0.25 < z["ulp_inside__terms"][0, 0, 0] < 0.25 + 1e-7 and z["ulp_outside__terms"][0, 0, 0] == 0.0
+    assert np.all(z["ulp_inside__obs"][0, 0, 5:9] != -1.0) and np.all(z["ulp_outside__obs"][0, 0, 5:9] == -1.0)
+    # UAV 1 sees UAV 0 at dc -+ 2^-14: its communication mean changes; UAV 0's duplicate term loses UAV 2 at 2 dp + 2^-15
+    assert not np.allclose(z["ulp_inside__obs"][0, 1, :5], z["ulp_outside__obs"][0, 1, :5])
+    assert z["ulp_inside__terms"][0, 2, 0] < z["ulp_outside__terms"][0, 2, 0]
+    for name in ("ulp_inside", "ulp_outside"):
+        env = OracleEnv(OracleConfig(n_envs=1, n_uav=4, m_targets=2, cooperative=0.3))
+        env.set_state(*(z[f"{name}__{k}"][0][None] for k in ("ux", "uy", "uh", "ua", "tx", "ty", "th")))
+        out = env.step(z[f"{name}__actions"][0][None])
+        # UAVs 0-2 hold a dp / dc / 2 dp test one ulp from its threshold; UAV 3's only knife edge is the NEIGHBOUR test against
+        # UAV 0, which moves cooperative rewards, not its own row: it shows in the environment's margin alone
+        assert out["margin"][0] <= 2.0 ** -15 and np.all(out["margin_row"][0, :3] <= 2.0 ** -14 + 1e-12)
+        assert out["margin_row"][0, 3] > 1.0
+        assert np.all(out["margin_row"][0] >= out["margin"][0])
+    # margins of an ordinary batch: the environment's margin is the minimum over every test, so no row lies below it
+    env = OracleEnv(OracleConfig(n_envs=64, n_uav=20, m_targets=10, cooperative=0.3), n_threads=4)
+    env.reset_philox(seed=3)
+    rng = np.random.RandomState(0)
+    for t in range(10):
+        out = env.step(rng.randint(0, 12, size=(64, 20)))
+        assert np.all(out["margin_row"].min(1) >= out["margin"])
+        assert np.all(np.isfinite(out["margin_row"]))
+
+
 def test_edge_case_semantics():
     """The goldens really exercise the quirks they are named for."""
     z, _ = load_golden("g7_edges")
