@@ -493,8 +493,12 @@ def pmi_roofline(args, roof, units_per_launch):
             traffic, traffic_src = ent["hbm_bytes_per_launch"], ent.get("source")
     except Exception:
         pass
+    # what the scorer must move per pair: its 8-byte record, the two 48-byte observation rows, the 4-byte score
+    alg_bytes = 108.0 * pairs / max(1, roof["launches"])
     common = {
-        "traffic": traffic, "traffic_source": traffic_src, "flop_per_pair": flop_pair, "pairs_scored": pairs,
+        "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
+        "physical_hbm_frac": None if traffic is None else traffic / (scorer_s / roof["launches"]) / 1e9 / HBM_PEAK_GBS,
+        "flop_per_pair": flop_pair, "pairs_scored": pairs,
         "pairs_per_agent_step": pairs / (units_per_launch * roof["launches"]),
         "rescored_chunks": (roof.get("pmi_info") or {}).get("rescored_chunks", 0),
         "scorer_ms_per_launch": scorer_s * 1e3 / roof["launches"],
@@ -534,6 +538,11 @@ def hbm_roofline(args, roof, B, N, M):
         "bound": "hbm", "kernel": "rollout_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
         "traffic": traffic, "algorithmic_bytes_per_agent_step": bytes_unit, "agent_steps_per_launch": units,
+        "algorithmic_bytes_per_launch": bytes_unit * units,
+        # `frac` prices the ALGORITHMIC bytes of SURVEY 8d; the fused rollout keeps the state on chip, so the bytes that
+        # really cross the HBM interface (PMC counters of this launch shape, profiles/) are fewer: this is that stream's rate
+        "physical_GBs": None if traffic is None else traffic / (kern_ms * 1e-3) / 1e9,
+        "physical_frac": None if traffic is None else traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "kernel_avg_ms": kern_ms,
         "frac_at_median_call": bytes_unit * units / (roof["median_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "frac_at_slowest_call": bytes_unit * units / (roof["max_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -670,10 +679,13 @@ def extras(uavtrack, args, B, device, bytes_unit):
     Bs, Ts = 65536, (200 if free_b > (64 << 30) else 50)
     rs = roofline_leg(uavtrack, args, Bs, device, T=Ts, launches=4)
     ach = bytes_unit * Bs * N * Ts / (rs["avg_ms"] * 1e-3) / 1e9
+    sat_traffic, _ = lookup_traffic(Bs, N, M, Ts, args)
     out["saturating_batch"] = {
         "workload": f"{Bs} envs x {N} UAVs x {M} targets, {Ts} steps per launch",
         "agent_steps_per_s": Bs * N * Ts / (rs["avg_ms"] * 1e-3),
         "roofline_achieved_GBs": ach, "roofline_frac": ach / HBM_PEAK_GBS,
+        "traffic": sat_traffic, "algorithmic_bytes_per_launch": bytes_unit * Bs * N * Ts,
+        "physical_frac": None if sat_traffic is None else sat_traffic / (rs["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "avg_launch_ms": rs["avg_ms"], "geometry": rs["geometry"],
     }
     # closed loop: actor forward [B*N,12] -> sample -> uavtrack_step per step, eager
@@ -758,7 +770,54 @@ def extras(uavtrack, args, B, device, bytes_unit):
                   "greedy_graph / greedy_fused = the same two forms with the reference's C-METHOD baseline policy "
                   "(uav.py:324-369) instead of the actor")
     out["closed_loop"] = cl
+    out["compat"] = compat_leg(uavtrack)
     return out
+
+
+# the unmodified reference's Environment.step, timed in the build container (Intel Xeon 2.10 GHz,
+# ONE core -- the reference is single-threaded Python; it cannot travel to the GPU box), ms per step
+REFERENCE_STEP_MS = {"1x5x3 MAAC": 0.56, "1x20x10 MAAC": 2.40, "1x20x10 MAAC-G": 1.54, "1x20x10 MAAC-R H=128": 6.32, "1x50x25 MAAC": 5.06}
+
+
+def compat_leg(uavtrack, steps=300, warm=60):
+    """The loop the reference really runs (train.py:160-185): ONE environment, one `env.step(config, pmi, actions)` per step
+    on the drop-in `uavtrack.Environment`, with the N `uav.get_local_state()` calls of train.py:165-166 in front of it --
+    host lists in, host lists out.  Wall microseconds per step, beside the reference's own figure."""
+    import random
+
+    class Pmi:                                   # what Environment.step needs of a PMINetwork: truthiness and a state_dict
+        def state_dict(self):
+            return synthetic_pmi_state_dict(128, 42)
+    out = []
+    for name, n, m, coop, pmi in (("1x5x3 MAAC", 5, 3, 0.0, None), ("1x20x10 MAAC", 20, 10, 0.0, None), ("1x20x10 MAAC-G", 20, 10, 0.3, None),
+                                  ("1x20x10 MAAC-R H=128", 20, 10, 0.3, Pmi()), ("1x50x25 MAAC", 50, 25, 0.0, None)):
+        cfg = {"environment": {"n_uav": n, "m_targets": m, "x_max": 2000, "y_max": 2000, "na": 12},
+               "uav": {"dt": 1, "v_max": 20, "h_max": 6, "dc": 500, "dp": 200, "alpha": 0.6, "beta": 0.2, "gamma": 0.2},
+               "target": {"v_max": 5, "h_max": 6}, "cooperative": coop}
+        env = uavtrack.Environment(n_uav=n, m_targets=m, x_max=2000, y_max=2000, na=12)
+        random.seed(42)
+        env.reset(config=cfg)
+        acts = [[random.randint(0, 11) for _ in range(n)] for _ in range(warm + steps)]
+
+        def run(k0, k1):
+            for k in range(k0, k1):
+                states = [u.get_local_state() for u in env.uav_list]          # train.py:165-166
+                env.step(cfg, pmi, acts[k])                                   # train.py:176
+            return states
+        run(0, warm)
+        runs = []
+        for _ in range(3):                       # (a shared box: the best of three is the adapter's own cost)
+            t0 = time.perf_counter()
+            run(warm, warm + steps)
+            runs.append((time.perf_counter() - t0) / steps * 1e6)
+        us = min(runs)
+        out.append({"cfg": name, "us_per_step": us, "us_per_step_all_runs": runs, "agent_steps_per_s": n / (us * 1e-6),
+                    "reference_ms_per_step": REFERENCE_STEP_MS[name], "speedup_vs_reference": REFERENCE_STEP_MS[name] * 1e3 / us})
+        env._env.close()
+    return {"what": "uavtrack.Environment (B = 1): N get_local_state() calls + env.step(config, pmi, actions) per step, wall time; "
+                    "one uavtrack_step_host call per step",
+            "reference": "BASELINE.md section 2: the unmodified reference on 1 core of the build container's Xeon 2.10 GHz (no GPU)",
+            "shapes": out}
 
 
 def configs_summary(line, B, N, M, args):
@@ -770,12 +829,16 @@ def configs_summary(line, B, N, M, args):
     out = [{"cfg": f"{B}x{N}x{M} {args.dim}D {args.reward} (timed region)", "G": r3(line["value"] / 1e9), "ms_per_step": r3(line["ms_per_step"]),
             "frac": r3(rl["frac"]), "bound": rl["bound"], "kernel_ms": r3(rl.get("kernel_avg_ms", rl.get("scorer_ms_per_launch"))),
             "roofline_leg_G": r3(B * N * rl["steps_per_launch"] / (rl["avg_launch_ms"] * 1e-3) / 1e9)}]
+    if rl.get("physical_frac") is not None:
+        out[0]["phys"] = r3(rl["physical_frac"])        # HBM bytes by the PMC counters / kernel time / 8 TB/s (frac: algorithmic bytes)
     for ent in line.get("other_configs") or []:
         if not isinstance(ent, dict) or "roofline" not in ent:
             continue
         r = ent["roofline"]
         e = {"cfg": ent["config"], "G": r3(ent["agent_steps_per_s"] / 1e9), "frac": r3(r["frac"]), "bound": r["bound"],
              "kernel_ms": r3(r.get("kernel_avg_ms", r.get("scorer_ms_per_launch"))), "call_ms": r3(r["avg_launch_ms"])}
+        if r.get("physical_frac") is not None:
+            e["phys"] = r3(r["physical_frac"])
         if "kernel_ms_per_launch" in r:
             e["kernels_ms"] = {k: r3(v) for k, v in r["kernel_ms_per_launch"].items()}
         out.append(e)
@@ -783,9 +846,14 @@ def configs_summary(line, B, N, M, args):
         sb = line["saturating_batch"]
         out.append({"cfg": "65536x20x10 2D raw (chip-filling)", "G": r3(sb["agent_steps_per_s"] / 1e9), "frac": r3(sb["roofline_frac"]),
                     "bound": "hbm", "kernel_ms": r3(sb["avg_launch_ms"])})
+        if sb.get("physical_frac") is not None:
+            out[-1]["phys"] = r3(sb["physical_frac"])
     if "closed_loop" in line:
         out.append({"cfg": "closed loop 4096x20x10, G agent-steps/s", **{k: r3(v["agent_steps_per_s"] / 1e9)
                                                                       for k, v in line["closed_loop"].items() if isinstance(v, dict) and "agent_steps_per_s" in v}})
+    if "compat" in line:
+        out.append({"cfg": "compat Environment.step B=1, us/step (reference ms/step)",
+                    **{c["cfg"][2:]: [r3(c["us_per_step"]), c["reference_ms_per_step"]] for c in line["compat"]["shapes"]}})
     if "per_step_launch" in line:
         out.append({"cfg": "T=1 launches", "G": r3(line["per_step_launch"]["agent_steps_per_s"] / 1e9), "us_per_step": r3(line["per_step_launch"]["ms_per_step"] * 1e3)})
     return out
