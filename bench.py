@@ -76,8 +76,10 @@ def parse(argv=None):
     ap.add_argument("--pmi-scheme", choices=["auto", "f16x3", "bf16x6", "fp32"], default="auto",
                     help="pin the MAAC-R pair scorer (uavtrack_set_pmi_scheme); auto = the fastest the weights allow")
     ap.add_argument("--verbose", action="store_true", help="keep the per-launch arrays and the prose notes on the line")
-    ap.add_argument("--gather-transitions", type=int, default=4096,
-                    help="N > 1: transitions each rank samples per rollout for the learner-side all-gather (0 = summary gather only)")
+    ap.add_argument("--gather-transitions", type=int, default=0,
+                    help="transitions every rank samples per rollout for the learner-side all-gather (SURVEY 8e's optional second "
+                         "exchange; 0 = the end-of-rollout summary gather only, which is what north_star names).  The sampling runs at "
+                         "ANY world size, so the N = 1 line carries the same per-rollout work as the N > 1 lines")
     ap.add_argument("--rollout", type=int, default=200, help="steps per fused launch (1 = one launch per step)")
     ap.add_argument("--policy", choices=["given", "greedy", "actor"], default="given",
                     help="where actions come from: pre-sampled (the headline workload), the fused greedy baseline "
@@ -125,6 +127,10 @@ def spawn_ranks(args, argv):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # like torchrun: one OpenMP thread per rank unless the caller says otherwise.  os.cpu_count() reports the whole host
+        # (256 on the GPU boxes) while the cgroup grants 16 cores: N ranks each spinning a 128-thread pool starve the
+        # collective's own threads (the gloo rehearsal: 200 ms per 458 KB gather)
+        env.setdefault("OMP_NUM_THREADS", "1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=None if r == 0 else sys.stderr))
     rc = 0
@@ -160,7 +166,13 @@ def launcher_selftest(args, world, rank):
     else:
         ws = 1
     if rank == 0:
-        print(json.dumps({"selftest": "launcher", "n_gpus": world, "rccl_world_size": ws, "gpus_requested": args.gpus}), flush=True)
+        # the timed region's launches and gathers as time_config() would issue them with these flags (pure host logic)
+        warm_plan, pos = launch_plan(args.warmup, args.rollout, ROOFLINE_T, 0)
+        timed_plan, _ = launch_plan(args.steps, args.rollout, ROOFLINE_T, pos)
+        print(json.dumps({"selftest": "launcher", "n_gpus": world, "rccl_world_size": ws, "gpus_requested": args.gpus,
+                          "timed_launch_steps": timed_plan,
+                          "gather": {"in_region": len(gather_points(timed_plan, pos, ROOFLINE_T)),
+                                     "behind_launches": gather_points(timed_plan, pos, ROOFLINE_T)}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -218,6 +230,21 @@ def launch_plan(steps, rollout, horizon, ep_steps):
     return plan, ep_steps
 
 
+def gather_points(plan, ep_steps, horizon):
+    """Indices of the launches of `plan` behind which the end-of-rollout gather runs: every launch that ends an episode,
+    and the LAST launch whatever it ends on -- the K steps of a timed region are a rollout, and its summaries are gathered
+    before the clock stops (at the driver's --steps 20 that is exactly one gather, behind the one launch)."""
+    pts = []
+    for k, T in enumerate(plan):
+        ep_steps += T
+        if ep_steps >= horizon:
+            pts.append(k)
+            ep_steps = 0
+    if plan and (not pts or pts[-1] != len(plan) - 1):
+        pts.append(len(plan) - 1)
+    return pts
+
+
 def describe_plan(plan):
     """'3 x 200 + 1 x 20' -- the launches of a plan, in order, run-length encoded."""
     runs = []
@@ -244,11 +271,12 @@ def alloc_outputs(args, B, T, device):
 
 
 def run_rollouts(env, actions, plan, ep_steps, out, gather=None, policy="given", obs=None, bound=None):
-    """Issue the launches of `plan`; gathers the episode summaries and resets at every episode end.
+    """Issue the launches of `plan`; gathers the rollout summaries at gather_points() and resets at every episode end.
     obs: the observation the in-kernel policy sees first (policy != "given").
     bound: pre-built launch callables from bind_plan (the timed region replays those: no per-call Python beyond the
     ctypes call itself)."""
     horizon = env.cfg.horizon
+    gather_at = set(gather_points(plan, ep_steps, horizon)) if gather is not None else set()
     for k, T in enumerate(plan):
         if bound is not None:
             res = bound["launch"][k]()
@@ -261,9 +289,9 @@ def run_rollouts(env, actions, plan, ep_steps, out, gather=None, policy="given",
             res = env.step_many(actions[ep_steps:ep_steps + T], out=out.get(T))   # the episode's own action rows
         out[T] = res
         ep_steps += T
-        if ep_steps >= horizon:               # end of an episode: gather summaries (and sampled transitions), start the next one
-            if gather is not None:
-                gather(res, None if actions is None else actions[ep_steps - T:ep_steps])
+        if k in gather_at:                    # end of a rollout: gather its summaries (and sampled transitions)
+            gather(res, None if actions is None else actions[ep_steps - T:ep_steps])
+        if ep_steps >= horizon:               # end of an episode: start the next one
             if bound is not None:
                 bound["episode"] += 1
                 obs = bound["reset"](bound["episode"])
@@ -291,31 +319,36 @@ def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, en
     """The contract's timed region: `warmup` untimed steps, then exactly `steps` steps between
     barrier + synchronize.  Returns wall time, the plan that was timed and per-launch HIP-event times."""
     import torch
+    total_envs = total_envs or B
     env = make_env(uavtrack, args, B, device, env_offset)
     na_total = env.cfg.na_total
     g = torch.Generator(device=device).manual_seed(args.seed + env_offset)
     horizon = env.cfg.horizon
     actions = torch.randint(0, na_total, (horizon, B, args.n_uav), dtype=torch.int32, device=device, generator=g)
-    gather = None
+    multi = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
     gathered_bytes = [0, 0]          # per rank: episode summaries, sampled transitions
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        # asynchronous: the collectives run on RCCL's stream from private copies, the next rollout does not wait
-        # for them (nor for a slower rank); every handle is waited on before the clock stops
-        pending = []
-        k_tr = max(0, int(getattr(args, "gather_transitions", 0)))
-        tgen = torch.Generator(device=device).manual_seed(args.seed + 1000 + env_offset)
-        first_obs = torch.full((B, args.n_uav, 12), -1.0, device=device)
+    gathers = [0]                    # end-of-rollout gathers issued so far
+    # The end-of-rollout exchange (SURVEY 8e).  The SAME calls run at every world size: without a process group the two
+    # gather functions hand their input back (no copy, no collective), so the N = 1 line and the N > 1 lines differ by the
+    # collective and nothing else -- whatever host and stream work rides with it (the optional transition sampling) is on
+    # both.  Asynchronous: the collectives run on RCCL's stream from private copies, the next rollout does not wait for
+    # them (nor for a slower rank); every handle is waited on before the clock stops.
+    pending = []
+    k_tr = max(0, int(getattr(args, "gather_transitions", 0)))
+    tgen = torch.Generator(device=device).manual_seed(args.seed + 1000 + env_offset)
+    first_obs = torch.full((B, args.n_uav, 12), -1.0, device=device)
 
-        def gather(res, act_rows):
-            pending.append(uavtrack.gather_rollout_summary_async(res["ep_sums"], n_envs_total=total_envs))
-            gathered_bytes[0] += res["ep_sums"].numel() * 4
-            if k_tr and res.get("obs") is not None and res["reward"].shape[0] * B * args.n_uav >= k_tr:
-                # the learner-side exchange (SURVEY 8e): K sampled (state, action, reward, next_state) rows of this rollout
-                roll = dict(obs=res["obs"], reward=res["reward"], actions=res["actions"] if "actions" in res else act_rows)
-                smp = uavtrack.sample_local_transitions(first_obs, roll, k_tr, env_offset=env_offset, n_envs_total=total_envs, generator=tgen)
-                h = uavtrack.gather_transitions_async(smp)
-                pending.append(h)
-                gathered_bytes[1] += h.nbytes_per_rank
+    def gather(res, act_rows):
+        gathers[0] += 1
+        pending.append(uavtrack.gather_rollout_summary_async(res["ep_sums"], n_envs_total=total_envs))
+        gathered_bytes[0] += res["ep_sums"].numel() * 4
+        if k_tr and res.get("obs") is not None and res["reward"].shape[0] * B * args.n_uav >= k_tr:
+            # the learner-side exchange: K sampled (state, action, reward, next_state) rows of this rollout
+            roll = dict(obs=res["obs"], reward=res["reward"], actions=res["actions"] if "actions" in res else act_rows)
+            smp = uavtrack.sample_local_transitions(first_obs, roll, k_tr, env_offset=env_offset, n_envs_total=total_envs, generator=tgen)
+            h = uavtrack.gather_transitions_async(smp)
+            pending.append(h)
+            gathered_bytes[1] += h.nbytes_per_rank
     warm_plan, pos = launch_plan(warmup, rollout, horizon, 0)
     timed_plan, _ = launch_plan(steps, rollout, horizon, pos)
     # output buffers of every launch shape exist before the clock starts (allocation is not part of a step)
@@ -324,28 +357,31 @@ def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, en
     obs0 = env.reset(seed=args.seed)
     _, obs0 = run_rollouts(env, actions, warm_plan, 0, out, gather=gather, policy=args.policy, obs=obs0)
     bound = bind_plan(env, actions, timed_plan, pos, out, device) if args.policy == "given" else None
-    if gather is not None:
-        for h in pending:
-            h.wait()
-        pending.clear()
+    for h in pending:
+        h.wait()
+    pending.clear()
     torch.cuda.synchronize(device)
-    if gather is not None:
+    if multi:
         dist.barrier()
+    g0 = gathers[0]
+    gathered_bytes[0] = gathered_bytes[1] = 0
     t0 = time.perf_counter()
     launches, _ = run_rollouts(env, actions, timed_plan, pos, out, gather=gather, policy=args.policy, obs=obs0, bound=bound)
-    if gather is not None:
-        done_h = [h.wait() for h in pending]
-        assert all(s.shape[0] == total_envs for s in done_h if torch.is_tensor(s))
+    done_h = [h.wait() for h in pending]      # the gather behind the last launch included: it is part of the region
+    assert all(s.shape[0] == total_envs for s in done_h if torch.is_tensor(s))
     torch.cuda.synchronize(device)
     wall = time.perf_counter() - t0       # this rank's K steps (and every gather it took part in) are done; the caller takes the MAX over ranks
-    if gather is not None:
+    if multi:
         dist.barrier()                    # closing bracket: no rank leaves the region before the slowest has stopped its clock
+    in_region = gathers[0] - g0
+    assert in_region == len(gather_points(timed_plan, pos, horizon)) >= 1
     info = env.kernel_info()
     env.close()
     if warm is not None:
         warm.pop("keep")[0].close()
-    gather_info = None
-    if gather is not None:
+    gather_info = {"in_region": in_region, "collective": bool(multi),
+                   "timed_region_bytes_per_rank": {"summaries": gathered_bytes[0], "transitions": gathered_bytes[1]}}
+    if multi:
         # what the collectives cost on their own: blocking, back to back, outside the timed region (in it they overlap the next rollout)
         ep = torch.zeros(B, 5, device=device)
         def timed(fn, reps=5):
@@ -355,8 +391,8 @@ def time_config(uavtrack, args, B, steps, warmup, rollout, device, dist=None, en
                 fn()
             torch.cuda.synchronize(device)
             return (time.perf_counter() - t0) * 1e3 / reps
-        gather_info = {"summary_ms": timed(lambda: uavtrack.gather_rollout_summary(ep, n_envs_total=total_envs)),
-                       "summary_bytes_per_rank": B * 5 * 4, "timed_region_bytes_per_rank": {"summaries": gathered_bytes[0], "transitions": gathered_bytes[1]}}
+        gather_info.update({"summary_ms": timed(lambda: uavtrack.gather_rollout_summary(ep, n_envs_total=total_envs)),
+                            "summary_bytes_per_rank": B * 5 * 4})
         if k_tr:
             T0 = max(set(timed_plan), key=timed_plan.count)
             roll = dict(obs=out[T0]["obs"], reward=out[T0]["reward"], actions=actions[:T0] if "actions" not in out[T0] else out[T0]["actions"])
@@ -952,7 +988,8 @@ def worker(args):
                                      "Categorical sample (uavtrack_run_actor), closed loop"}[args.policy],
                 "outputs": "obs[T,B,N,12] reward[T,B,N] terms[T,3,B,N] covered[T,B] done[T,B] ep_sums[B,5], all written",
                 "parallelism": (f"env-sharded x{world}, {'RCCL' if args.backend == 'nccl' else args.backend} "
-                                f"all-gather of ep_sums per rollout, asynchronous (overlaps the next rollout)") if world > 1 else "1 GPU",
+                                f"all-gather of ep_sums behind every rollout -- {res['gather']['in_region']} inside the timed region, the one "
+                                f"behind its last launch included and waited for before the clock stops") if world > 1 else "1 GPU",
                 "geometry": res["geometry"],
                 "device_warmup": ("none (--no-device-warmup): the timed region starts from the GPU's idle power state" if res["device_warmup"] is None else
                                   f"{res['device_warmup']['launches']} untimed {res['device_warmup']['steps_per_launch']}-step launches of this workload on a "

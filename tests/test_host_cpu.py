@@ -394,6 +394,13 @@ def test_bench_launch_plan_and_cores():
     assert warm == [5] and timed == [20] and bench.describe_plan(timed) == "1 x 20 steps"
     assert bench.describe_plan([195, 200, 200, 5]) == "1 x 195 + 2 x 200 + 1 x 5 steps"
     assert 1 <= bench.host_cores() <= os.cpu_count()
+    # the end-of-rollout gathers of a plan: behind every launch that ends an episode, and behind the last launch in any case
+    assert bench.gather_points([20], 5, 200) == [0]
+    assert bench.gather_points([200] * 10, 0, 200) == list(range(10))
+    assert bench.gather_points([195, 200, 200, 5], 5, 200) == [0, 1, 2, 3]
+    assert bench.gather_points([64, 64, 64, 8, 64], 0, 200) == [3, 4]
+    assert bench.gather_points([1] * 400, 100, 200) == [99, 299, 399]
+    assert bench.gather_points([], 0, 200) == []
 
 
 def test_bench_gpus_n_starts_n_ranks_or_fails():
@@ -412,6 +419,13 @@ def test_bench_gpus_n_starts_n_ranks_or_fails():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["rccl_world_size"] == 2 and d["gpus_requested"] == 2
+    # with the driver's flags the timed region of an N > 1 run is ONE 20-step launch and exactly ONE
+    # end-of-rollout gather behind it (the rollout IS the K steps); the default flags gather behind every episode
+    r = subprocess.run(exe + ["--gpus", "2", "--backend", "gloo", "--selftest-launcher", "--steps", "20", "--warmup", "5"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["timed_launch_steps"] == [20] and d["gather"] == {"in_region": 1, "behind_launches": [0]}
     # a rank count that cannot be honoured is an error, never a silent 1-GPU run
     r = subprocess.run(exe + ["--gpus", "2", "--selftest-launcher"], capture_output=True, text=True, timeout=120,
                        env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
