@@ -176,7 +176,10 @@ constexpr float kActorCap = 60000.0f;       // inside f16's 65504 with room for 
 // EVERY lane of the wavefront must reach this call together (MFMA and the lane swaps ignore EXEC); lanes without a UAV
 // pass zeros and ignore the result.  weights: the blob; HT = actor_blocks(hidden).
 // mode: UAVTRACK_ACTOR_SAMPLE (inverse-CDF draw) or UAVTRACK_ACTOR_ARGMAX (lowest index on ties).
-template <bool WANT_PROBS, int AT>
+// HT_ > 0: the number of hidden tiles is known at compile time, and even (the caller checks HT == HT_): the tile loop takes two
+// tiles per trip with the fragment buffers taking turns (no copy of 24 registers per tile).  (A fully straight layout --
+// accumulators started from the MFMA's inline zero, immediate fragment addresses -- spilled: 208 bytes of scratch.)
+template <bool WANT_PROBS, int AT, int HT_ = 0>
 __device__ __forceinline__ int actor_pick(const float (&o)[kActorObs], const float *__restrict__ weights,
                                           int HT, int A, uint64_t genv, uint32_t step, int i, uint32_t k0, uint32_t k1,
                                           int mode, float *probs, ActorRng &rng)
@@ -222,8 +225,6 @@ __device__ __forceinline__ int actor_pick(const float (&o)[kActorObs], const flo
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
     actor_f16v d2[AT][2];
-#pragma unroll
-    for (int t = 0; t < AT; ++t) { d2[t][0] = zero16; d2[t][1] = zero16; }
     // The two layers as a software pipeline over the units (hidden tile a, column tile c): a wavefront issues in order, an
     // MFMA occupies the matrix pipe for 32 cycles but the issue port for 8, and the conversion of a finished layer-1 tile
     // into layer-2 operands is ~20 VALU instructions per half -- left to the compiler the MFMAs came in dependent groups of
@@ -250,11 +251,13 @@ __device__ __forceinline__ int actor_pick(const float (&o)[kActorObs], const flo
         else if constexpr (k < 12) cv.hh[k - 8] = actor_pk(cv.v[2 * (k - 8)], cv.v[2 * (k - 8) + 1]);
         else cv.hl[k - 12] = actor_rem(cv.hh[k - 12], cv.v[2 * (k - 12)], cv.v[2 * (k - 12) + 1]);
     };
-    auto layer2 = [&](const actor_u4 (&w)[FT], const Conv &cv, int c, int half, auto tc, auto kc) {
+    auto layer2 = [&](const actor_u4 (&w)[FT], const Conv &cv, int c, int half, auto tc, auto kc, auto firstc) {
         constexpr int t = decltype(tc)::value, k = decltype(kc)::value;
+        constexpr bool first = decltype(firstc)::value;      // the very first product of this accumulator: C = 0, nothing to clear
         const actor_h8 bh = actor_as_h8((actor_u4){cv.hh[0], cv.hh[1], cv.hh[2], cv.hh[3]}), bl = actor_as_h8((actor_u4){cv.hl[0], cv.hl[1], cv.hl[2], cv.hl[3]});
         const actor_h8 w2h = actor_as_h8(w[2 + 4 * t + 2 * half]), w2l = actor_as_h8(w[3 + 4 * t + 2 * half]);
-        if constexpr (k == 0) d2[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2l, bh, d2[t][c], 0, 0, 0);
+        if constexpr (k == 0 && first) d2[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2l, bh, zero16, 0, 0, 0);
+        else if constexpr (k == 0) d2[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2l, bh, d2[t][c], 0, 0, 0);
         else if constexpr (k == 1) d2[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h, bl, d2[t][c], 0, 0, 0);
         else d2[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h, bh, d2[t][c], 0, 0, 0);
         // (an MFMA is a pure value to the compiler and would sink to its only reader -- the end of the loop -- leaving the
@@ -262,7 +265,7 @@ __device__ __forceinline__ int actor_pick(const float (&o)[kActorObs], const flo
         asm volatile("" : "+v"(d2[t][c]));
     };
     // one unit: `dn` receives layer 1 of the next unit (fragments wn, column tile cn) while `dc` (this unit's) is converted
-    auto unit = [&](actor_f16v &dn, const actor_u4 (&wn)[FT], int cn, const actor_f16v &dc, const actor_u4 (&w)[FT], int c) {
+    auto unit = [&](actor_f16v &dn, const actor_u4 (&wn)[FT], int cn, const actor_f16v &dc, const actor_u4 (&w)[FT], int c, auto firstc) {
         Conv c0, c1;
         actor_static_for<3>([&](auto kc) {                        // phase A
             constexpr int k = decltype(kc)::value;
@@ -276,7 +279,7 @@ __device__ __forceinline__ int actor_pick(const float (&o)[kActorObs], const flo
         actor_static_for<AT>([&](auto tc) {                       // phase B (the conversion of half 1 rides behind action tile 0's MFMAs)
             actor_static_for<3>([&](auto kc) {
                 constexpr int k = decltype(kc)::value, t = decltype(tc)::value;
-                layer2(w, c0, c, 0, tc, kc);
+                layer2(w, c0, c, 0, tc, kc, firstc);
                 if constexpr (t == 0)
                     actor_static_for<16>([&](auto ac) {
                         constexpr int q = decltype(ac)::value;
@@ -287,24 +290,49 @@ __device__ __forceinline__ int actor_pick(const float (&o)[kActorObs], const flo
         });
         actor_static_for<AT>([&](auto tc) {                       // phase C
             actor_static_for<3>([&](auto kc) {
-                layer2(w, c1, c, 1, tc, kc);
+                layer2(w, c1, c, 1, tc, kc, std::false_type{});
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
     };
     actor_f16v da, db;                       // layer-1 accumulators of column tile 0 / 1 (they take turns)
     actor_static_for<3>([&](auto kc) { layer1(da, wf, 0, kc); });
-#pragma unroll 1
-    for (int a = 0; a < HT; ++a) {
-        actor_u4 nx[FT];
-        const int an = a + 1 < HT ? a + 1 : a;          // (the last iteration re-requests its own tile: no branch around loads,
-#pragma unroll                                          //  and its look-ahead layer 1 lands in an accumulator nobody reads)
-        for (int f = 0; f < FT; ++f) nx[f] = wl[((size_t)an * FT + f) * 64];
-        __builtin_amdgcn_sched_barrier(0);
-        unit(db, wf, 1, da, wf, 0);
-        unit(da, nx, 0, db, wf, 1);
+    if constexpr (HT_ > 0) {
+        // HT_ tiles, an even number: the tile loop runs two tiles per trip and the two fragment buffers take turns -- no copy of
+        // the 24 fragment registers per tile, and the trip count is known (no zero-trip path with its own register moves)
+        static_assert(HT_ % 2 == 0, "the two-tiles-per-trip layout needs an even tile count");
 #pragma unroll
-        for (int f = 0; f < FT; ++f) wf[f] = nx[f];
+        for (int t = 0; t < AT; ++t) { d2[t][0] = zero16; d2[t][1] = zero16; }
+        actor_u4 nx[FT];
+#pragma unroll 1
+        for (int a = 0; a < HT_; a += 2) {
+#pragma unroll
+            for (int f = 0; f < FT; ++f) nx[f] = wl[((size_t)(a + 1) * FT + f) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+            unit(db, wf, 1, da, wf, 0, std::false_type{});
+            unit(da, nx, 0, db, wf, 1, std::false_type{});
+            const int an = a + 2 < HT_ ? a + 2 : a + 1;      // (the last tile looks ahead at itself: that layer 1 lands in an accumulator nobody reads)
+#pragma unroll
+            for (int f = 0; f < FT; ++f) wf[f] = wl[((size_t)an * FT + f) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+            unit(db, nx, 1, da, nx, 0, std::false_type{});
+            unit(da, wf, 0, db, nx, 1, std::false_type{});
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < AT; ++t) { d2[t][0] = zero16; d2[t][1] = zero16; }
+#pragma unroll 1
+        for (int a = 0; a < HT; ++a) {
+            actor_u4 nx[FT];
+            const int an = a + 1 < HT ? a + 1 : a;          // (the last iteration re-requests its own tile: no branch around loads,
+#pragma unroll                                              //  and its look-ahead layer 1 lands in an accumulator nobody reads)
+            for (int f = 0; f < FT; ++f) nx[f] = wl[((size_t)an * FT + f) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+            unit(db, wf, 1, da, wf, 0, std::false_type{});
+            unit(da, nx, 0, db, wf, 1, std::false_type{});
+#pragma unroll
+            for (int f = 0; f < FT; ++f) wf[f] = nx[f];
+        }
     }
     // ---- logits to their own lane: register r of tile 0 against register r of tile 1; afterwards every lane holds, of ITS
     //      sample, action 32 t + (r & 3) + 8 (r >> 2) in the first and that action + 4 in the second

@@ -60,6 +60,7 @@ struct Acc {
     float dup;   // uav.py:214-229
 };
 
+constexpr int kLoneActorTiles = 4;         // hidden width 128 (configs/MAAC.yaml): the tile count the single-wavefront actor rollout is laid out for
 constexpr float kSymMagic = 12582912.0f;   // 1.5 * 2^23 = 0x4B400000
 constexpr float kFar = 1.0e18f;   // padding agent of an odd-sized pair: every range test fails, 0 * kFar = 0
 
@@ -858,8 +859,15 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         // ---- P0 (fused actor rollout only): take_action (actor_critic.py:138-148) on the UAV's own previous
         //      observation, still in registers -- no table, no barrier
         if (ACTOR) {     // whole wavefronts: the two layers run on the matrix cores (actor.h)
-            act = actor_pick<false, actor_tiles(Z3)>(o, p.actor_w, p.actor_hblocks, p.na_total, (uint64_t)(p.env_offset + b),
-                                    (uint32_t)count, i, p.greedy_k0, p.greedy_k1, p.actor_mode, nullptr, arng);
+            // (the single-wavefront variant -- the closed loop at the reference shape -- carries a straight layout of the tile
+            //  loop for the reference's hidden width ONLY, 128 = kLoneActorTiles tiles -- launch_rollout sends other widths to the
+            //  4-wave variants; both layouts in one kernel spilled)
+            if constexpr (LONE)
+                act = actor_pick<false, actor_tiles(Z3), kLoneActorTiles>(o, p.actor_w, kLoneActorTiles, p.na_total, (uint64_t)(p.env_offset + b),
+                                        (uint32_t)count, i, p.greedy_k0, p.greedy_k1, p.actor_mode, nullptr, arng);
+            else
+                act = actor_pick<false, actor_tiles(Z3)>(o, p.actor_w, p.actor_hblocks, p.na_total, (uint64_t)(p.env_offset + b),
+                                        (uint32_t)count, i, p.greedy_k0, p.greedy_k1, p.actor_mode, nullptr, arng);
             if (active && p.actions_out) out_store(at(p.actions_out + row, g32 * 4u), act);
         }
 
@@ -1508,10 +1516,10 @@ KernelFn pick_reward(int mode, bool z3)
 // The launches a single-wavefront (LONE) kernel variant exists for: pre-sampled actions with every output, or the fused
 // actor rollout; no extras, planar, a specialised shape up to 20 x 10 (what sweep_fast's prefetch is written for).
 constexpr bool lone_shape(int n_spec, int m_spec) { return n_spec > 0 && n_spec <= 20 && m_spec <= 10; }
-bool lone_variant_exists(int N, int M, bool z3, int policy, bool allout, bool extras)
+bool lone_variant_exists(int N, int M, bool z3, int policy, bool allout, bool extras, int actor_hblocks)
 {
     const bool shape = (N == 20 && M == 10) || (N == 10 && M == 10) || (N == 5 && M == 3);      // the specialised shapes that pass lone_shape()
-    return shape && !z3 && !extras && ((policy == kPolicyGiven && allout) || policy == kPolicyActor);
+    return shape && !z3 && !extras && ((policy == kPolicyGiven && allout) || (policy == kPolicyActor && actor_hblocks == kLoneActorTiles));
 }
 
 // Instantiations: pre-sampled actions with every output and no extras (the learner's rollout, the benchmark);
@@ -1640,13 +1648,15 @@ hipError_t launch_rollout(uavtrack_env *env, const StepParams &p, hipStream_t st
     // Every other launch -- an output not requested, the target trace, the automatic reset -- would run the 4-wave emission
     // path (one pair-list reservation per workgroup-step on ONE counter) on four times the workgroups: measured 15.8
     // against 5.2 us per step at 4096 envs.  Those launches keep the 256-thread geometry.
-    if (!geo && env->cfg.reward_mode == UAVTRACK_REWARD_PMI && env->geo.lone &&
-        !lone_variant_exists(p.N, p.M, env->cfg.dim == 3, policy, allout, extras))
+    const bool lone_ok = lone_variant_exists(p.N, p.M, env->cfg.dim == 3, policy, allout, extras, p.actor_hblocks);
+    if (!geo && env->cfg.reward_mode == UAVTRACK_REWARD_PMI && env->geo.lone && !lone_ok)
         geo = &env->geo_short;
     const Geometry &g = geo ? *geo : env->geo;
     env->last_launch = g;
-    env->last_launch.lone = g.lone && lone_variant_exists(p.N, p.M, env->cfg.dim == 3, policy, allout, extras);
-    KernelFn fn = pick_kernel(p.N, p.M, env->cfg.reward_mode, env->cfg.dim == 3, &spec, policy, allout, extras, g.lone != 0);
+    env->last_launch.lone = g.lone && lone_ok;
+    // (an actor of another width than the single-wavefront variant is laid out for runs the general variant on the same geometry)
+    const bool lone_kernel = g.lone != 0 && !(policy == kPolicyActor && p.actor_hblocks != kLoneActorTiles);
+    KernelFn fn = pick_kernel(p.N, p.M, env->cfg.reward_mode, env->cfg.dim == 3, &spec, policy, allout, extras, lone_kernel);
     StepParams q = p;
     q.E = g.envs_per_wg;
     const size_t lds = rollout_lds_bytes(g, policy);
