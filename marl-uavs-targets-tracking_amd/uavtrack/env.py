@@ -395,18 +395,22 @@ class BatchedUavEnv:
         return a
 
     def run_greedy(self, T: int, seed: int = 0, want_obs: bool = True, want_terms: bool = True,
-                   want_actions: bool = True, want_targets: bool = False) -> Dict[str, torch.Tensor]:
-        """T closed-loop steps of the C-METHOD baseline (train.py:326-370) in one launch."""
-        def buf(shape, dtype, want=True):
-            return self._empty(shape, dtype) if want else None
-        acts = buf((T, self.B, self.N), torch.int32, want_actions)
-        obs = buf((T, self.B, self.N, _lib.OBS_DIM), torch.float32, want_obs)
-        reward = buf((T, self.B, self.N), torch.float32)
-        terms = buf((T, 3, self.B, self.N), torch.float32, want_terms)
-        covered = buf((T, self.B), torch.int32)
-        done = buf((T, self.B), torch.uint8)
-        ep = buf((self.B, 5), torch.float32)
-        tp = self._with_targets(T, want_targets, None, lambda: _lib.check(
+                   want_actions: bool = True, want_targets: bool = False,
+                   out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """T closed-loop steps of the C-METHOD baseline (train.py:326-370) in one launch.  Pass a previous result as
+        `out` to reuse its buffers."""
+        o = out or {}
+
+        def buf(key, shape, dtype, want=True):
+            return self._reuse(o, key, shape, dtype, want)
+        acts = buf("actions", (T, self.B, self.N), torch.int32, want_actions)
+        obs = buf("obs", (T, self.B, self.N, _lib.OBS_DIM), torch.float32, want_obs)
+        reward = buf("reward", (T, self.B, self.N), torch.float32)
+        terms = buf("terms", (T, 3, self.B, self.N), torch.float32, want_terms)
+        covered = buf("covered", (T, self.B), torch.int32)
+        done = buf("done", (T, self.B), torch.uint8)
+        ep = buf("ep_sums", (self.B, 5), torch.float32)
+        tp = self._with_targets(T, want_targets, o, lambda: _lib.check(
             self._lib.uavtrack_run_greedy(self._h, C.c_int32(T), C.c_uint64(seed & (2 ** 64 - 1)), _ptr(acts), _ptr(obs),
                                           _ptr(reward), _ptr(terms), _ptr(covered), _ptr(done), _ptr(ep), self._stream()),
             "uavtrack_run_greedy"))
@@ -474,6 +478,40 @@ class BatchedUavEnv:
         if tp is not None:
             res["targets"] = tp
         return res
+
+    def bind_run(self, T: int, out: Dict[str, torch.Tensor], policy: str = "actor", obs_in: Optional[torch.Tensor] = None,
+                 seed: int = 0, mode: int = _lib.ACTOR_SAMPLE):
+        """A zero-argument callable that issues `uavtrack_run_actor` / `uavtrack_run_greedy` (T steps, policy inside the
+        kernel) into `out` on the stream current NOW, with every ctypes argument built once -- what a driver that issues
+        short fused chunks replays (the per-call Python of run_actor is a visible share of a 10-step launch)."""
+        shapes = dict(actions=((T, self.B, self.N), torch.int32), obs=((T, self.B, self.N, _lib.OBS_DIM), torch.float32),
+                      reward=((T, self.B, self.N), torch.float32), terms=((T, 3, self.B, self.N), torch.float32),
+                      covered=((T, self.B), torch.int32), done=((T, self.B), torch.uint8), ep_sums=((self.B, 5), torch.float32))
+        for k, (shape, dtype) in shapes.items():
+            if out.get(k) is not None and not self._fits(out[k], shape, dtype):
+                raise ValueError(f"out[{k!r}] must be a contiguous {dtype} {shape} tensor on {self.device}")
+        if out.get("reward") is None:
+            raise ValueError("out['reward'] is required")
+        tail = (_ptr(out.get("actions")), _ptr(out.get("obs")), _ptr(out["reward"]), _ptr(out.get("terms")), _ptr(out.get("covered")),
+                _ptr(out.get("done")), _ptr(out.get("ep_sums")), self._stream())
+        s64 = C.c_uint64(seed & (2 ** 64 - 1))
+        if policy == "actor":
+            if not self._fits(obs_in, (self.B, self.N, _lib.OBS_DIM), torch.float32):
+                raise ValueError("obs_in must be a contiguous float32 [B, N, 12] tensor on this device")
+            fn, name = self._lib.uavtrack_run_actor, "uavtrack_run_actor"
+            args = (self._h, C.c_int32(T), s64, C.c_int32(mode), _ptr(obs_in)) + tail
+        elif policy == "greedy":
+            fn, name = self._lib.uavtrack_run_greedy, "uavtrack_run_greedy"
+            args = (self._h, C.c_int32(T), s64) + tail
+        else:
+            raise ValueError("policy must be 'actor' or 'greedy'")
+        keep = (out, obs_in)
+
+        def call():
+            if fn(*args) != 0:
+                _lib.check(1, name)
+            return keep[0]
+        return call
 
     @staticmethod
     def clip_saturation(terms: torch.Tensor, reward: torch.Tensor) -> Dict[str, int]:

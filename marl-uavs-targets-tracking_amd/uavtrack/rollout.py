@@ -67,6 +67,10 @@ class BatchedRollout:
         self.ep = torch.zeros(B, 5, device=dev)                        # sum_t mean_i reward, 3 terms, covered
         self.last_reward = torch.empty(B, env.N, device=dev)
         self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._ep_ring: Optional[torch.Tensor] = None                   # fuse_chunks: one row of episode sums per chunk of a run()
+        self._ep_used = 0
+        self._bound: Dict[int, Callable] = {}
+        self._chunk_ready = False
 
     # one closed-loop step on the current stream; everything stays on the device
     def _one_step(self):
@@ -112,11 +116,15 @@ class BatchedRollout:
         """Advance `steps` closed-loop steps; returns the episode accumulators so far."""
         done = 0
         if self.fuse_chunks:
+            self._ep_used = 0
             while steps - done >= self.k:
                 self._fused_chunk(self.k)
                 done += self.k
             if steps - done:
                 self._fused_chunk(steps - done)
+            if self._ep_used:          # the chunks' episode sums, added up ONCE per run() (one small kernel, not one per chunk)
+                self.ep += self._ep_ring[:self._ep_used].sum(dim=0)
+                self._ep_used = 0
             return {"ep_sums": self.ep, "obs": self.obs, "reward": self.last_reward}
         if self.use_graph and steps >= self.k:
             if self._graph is None:
@@ -129,17 +137,43 @@ class BatchedRollout:
         return {"ep_sums": self.ep, "obs": self.obs, "reward": self.last_reward}
 
     def _fused_chunk(self, k: int):
-        """k closed-loop steps of the library policy + environment in one launch; state of the driver as after k _one_step()."""
+        """k closed-loop steps of the library policy + environment in one launch; state of the driver as after k _one_step().
+        Nothing but the launch is issued per chunk: `obs` / `last_reward` become VIEWS of the chunk's last rows (the next
+        launch reads its first observation from there -- each lane reads its own row once, before it writes anything, and
+        that row is only rewritten by the same lane at the chunk's last step), and the chunk's episode sums go to their own
+        row of a ring that run() adds up at the end.  (Three small torch kernels per chunk cost as much as two steps.)"""
+        ring = self._ep_ring
+        if ring is None or self._ep_used >= ring.shape[0]:
+            if ring is not None:                      # a very long run(): fold what the ring holds and start over
+                self.ep += ring[:self._ep_used].sum(dim=0)
+            else:
+                self._ep_ring = ring = torch.empty(256, self.env.B, 5, device=self.env.device)
+            self._ep_used = 0
+        ep_row = ring[self._ep_used]
+        self._ep_used += 1
+        out = self._chunk_out if self._chunk_out is not None and self._chunk_out["reward"].shape[0] == k else None
+        if out is not None and k == self.k and self._chunk_ready:
+            # steady state: a pre-built library call per ring row (the chunk's buffers, its first observation = the previous
+            # chunk's last row, its episode-sum row are all fixed addresses)
+            call = self._bound.get(self._ep_used - 1)
+            if call is None:
+                call = self._bound[self._ep_used - 1] = self.env.bind_run(
+                    k, dict(out, ep_sums=ep_row), "actor" if self.device_actor else "greedy", obs_in=self.obs, seed=self.seed)
+            call()
+            return
+        if out is not None:
+            out = dict(out, ep_sums=ep_row)
         if self.device_actor:
-            out = self._chunk_out if self._chunk_out is not None and self._chunk_out["reward"].shape[0] == k else None
             res = self.env.run_actor(k, self.obs, seed=self.seed, want_terms=True, out=out)
-            if out is None and k == self.k:
-                self._chunk_out = res
         else:
-            res = self.env.run_greedy(k, seed=self.seed, want_actions=False)
-        self.obs.copy_(res["obs"][-1])
-        self.last_reward.copy_(res["reward"][-1])
-        self.ep += res["ep_sums"]
+            res = self.env.run_greedy(k, seed=self.seed, want_actions=False, out=out)
+        if out is None:
+            ep_row.copy_(res["ep_sums"])
+            if k == self.k:
+                self._chunk_out = res
+        self.obs = res["obs"][-1]
+        self.last_reward = res["reward"][-1]
+        self._chunk_ready = out is not None        # from now on obs / last_reward are the views the bound calls were built on
 
     def sync_actor(self):
         """Upload the policy's current parameters to the library (device_actor mode; after a learner update)."""

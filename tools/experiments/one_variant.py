@@ -1,14 +1,18 @@
 #!/usr/bin/env python3
 """Experiment aid (build container): compile ONE rollout_kernel instantiation to assembly in seconds instead of the whole
-step_kernel.hip in minutes.  usage: one_variant.py "20, 10, 0, false, 2, false, false, true" [out.s]
+step_kernel.hip in minutes.  usage: one_variant.py "20, 10, 0, false, 2, false, false, true" [out.s ["old=>new" ...]]
 Works on a patched COPY of csrc/step_kernel.hip whose pick_kernel() names only that variant; prints registers / scratch."""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 src = os.path.join(ROOT, "marl-uavs-targets-tracking_amd", "csrc")
 args = sys.argv[1]
 out = sys.argv[2] if len(sys.argv) > 2 else "/tmp/asm/one.s"
+subs = [a.split("=>", 1) for a in sys.argv[3:]]          # textual patches "old=>new" applied to the copy (experiments)
 os.makedirs(os.path.dirname(out), exist_ok=True)
 s = open(os.path.join(src, "step_kernel.hip")).read()
+for old, new in subs:
+    assert s.count(old) >= 1, old
+    s = s.replace(old, new)
 a = s.index("KernelFn pick_kernel(int N, int M, int mode, bool z3, int *specialised")
 b = s.index("}  // namespace\n\nGeometry plan_geometry")
 s = s[:a] + ("KernelFn pick_kernel(int N, int M, int mode, bool z3, int *specialised, int policy = kPolicyGiven, bool allout = false,\n"
