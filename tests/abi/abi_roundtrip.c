@@ -2,7 +2,8 @@
  * Builds with `gcc` against libamdhip64 (device memory + stream only) and libuavtrack.so.
  * Creates B environments, resets them, takes T single steps with a fixed action pattern and prints
  * FNV-1a checksums of the last observation / reward buffers plus the covered-target total, which the
- * GPU test compares with the Python host layer driving the same library (tests/test_hip_parity.py).
+ * GPU test compares with the Python host layer driving the same library (tests/test_hip_parity.py); then one step through
+ * uavtrack_step_host (host pointers in and out), whose checksums go on a second line.
  * usage: abi_roundtrip [B N M T seed]   (without a GPU it exits 3 after printing uavtrack_last_error) */
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
@@ -74,6 +75,18 @@ int main(int argc, char **argv)
     HIP_OK(hipMemcpy(h_rew, d_rew, BN * 4, hipMemcpyDeviceToHost));
     printf("obs %016llx reward %016llx covered %ld\n", (unsigned long long)fnv1a(h_obs, BN * UAVTRACK_OBS_DIM * 4),
            (unsigned long long)fnv1a(h_rew, BN * 4), covered_total);
+    /* one more step the way the reference's own loop calls Environment.step: HOST actions in, HOST results out
+     * (uavtrack_step_host: no device buffer, no copy call on the caller's side) -- second line of output */
+    {
+        uavtrack_host_step hs;
+        long cov = 0;
+        for (size_t g = 0; g < BN; ++g) h_act[g] = (int32_t)((g * 5 + 1) % 12);
+        UAV_OK(uavtrack_step_host(env, h_act, &hs, st));
+        for (int b = 0; b < B; ++b) cov += hs.covered[b];
+        printf("host obs %016llx reward %016llx raw %016llx ux %016llx covered %ld ua0 %d\n",
+               (unsigned long long)fnv1a(hs.obs, BN * UAVTRACK_OBS_DIM * 4), (unsigned long long)fnv1a(hs.reward, BN * 4),
+               (unsigned long long)fnv1a(hs.raw, BN * 4), (unsigned long long)fnv1a(hs.ux, BN * 4), cov, (int)hs.ua[0]);
+    }
     UAV_OK(uavtrack_destroy(env));
     return 0;
 }

@@ -992,6 +992,14 @@ def test_plain_c_client_matches_python_host_layer(uavtrack, tmp_path):
     assert got[1] == f"{fnv1a(obs.cpu().numpy().tobytes()):016x}"
     assert got[3] == f"{fnv1a(rew.cpu().numpy().tobytes()):016x}"
     assert int(got[5]) == covered
+    # second line: one uavtrack_step_host from there (host actions in, host results out), against the Python layer's step_host
+    host_line = r.stdout.splitlines()[1].split()
+    assert host_line[0] == "host"
+    v = env.step_host(((g * 5 + 1) % 12).astype(np.int32).reshape(B, N))
+    want = {"obs": v["obs"], "reward": v["reward"], "raw": v["raw"], "ux": v["ux"]}
+    for k, name in enumerate(("obs", "reward", "raw", "ux")):
+        assert host_line[2 + 2 * k] == f"{fnv1a(np.ascontiguousarray(want[name]).tobytes()):016x}", name
+    assert int(host_line[10]) == int(v["covered"].sum()) and int(host_line[12]) == int(v["ua"][0, 0]) == 1
 
 
 def test_bench_contract_line(uavtrack):
