@@ -283,7 +283,8 @@ int uavtrack_set_raw_reward_output(uavtrack_env *env, float *raw, int32_t capaci
  * library-owned, page-locked host block that the kernels write directly through its device mapping (no device-to-host
  * copy call), together with a copy of the state as it stands behind the step (what Environment.step appends to
  * `position`, environment.py:150-155, and what callers read as uav.x / target.x).  `out` receives HOST pointers into that
- * block; they stay valid, and are overwritten, until the next uavtrack_step_host or uavtrack_destroy on the handle.
+ * block; the block is allocated once per handle, so the pointers are the same on every call and stay valid -- their
+ * contents overwritten by the next uavtrack_step_host -- until uavtrack_destroy.
  * This entry point SYNCHRONISES `stream` before it returns (the one stepping call that does): it is meant for batches
  * of one or a few environments -- the drop-in adapter -- where a step is bound by the launch and the synchronisation,
  * not by the kernel.  Batched rollouts use uavtrack_step / uavtrack_step_many on device buffers. */

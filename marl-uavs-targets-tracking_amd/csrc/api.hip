@@ -260,14 +260,6 @@ void fold_constants(const uavtrack_config &c, StepParams &p, float *climb_c, flo
 }
 
 // ---- Environment.step for a HOST caller (uavtrack_step_host) ----------------------------------------------------
-// the state slab, as it stands behind the step, into the host block (one launch: a small device-to-host hipMemcpyAsync
-// costs more than a kernel that writes the mapped block directly)
-__global__ void __launch_bounds__(256) state_snapshot_kernel(const uint32_t *__restrict__ slab, uint32_t *__restrict__ dst, size_t n)
-{
-    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (k < n) __builtin_nontemporal_store(slab[k], dst + k);
-}
-
 struct HostLayout {      // offsets into the host block, in 4-byte units
     size_t actions, obs, reward, terms, raw, covered, done, state, total;
 };
@@ -707,6 +699,7 @@ static int run_steps(uavtrack_env *env, int32_t T, const int32_t *actions, float
     p.actions = actions;
     p.tpos = env->tpos;
     p.raw = env->raw_out;
+    p.state_copy = env->state_copy_out;
     p.obs = obs; p.reward = reward; p.terms = terms; p.nbrec = nullptr;
     p.covered = covered; p.done = done; p.ep_sums = ep_sums;
     p.pairs = nullptr; p.pair_count = nullptr; p.pair_total = nullptr;
@@ -955,16 +948,14 @@ int uavtrack_step_host(uavtrack_env *env, const int32_t *actions_host, uavtrack_
     float *const raw_was = env->raw_out;
     const int32_t raw_steps_was = env->raw_steps;
     env->raw_out = reinterpret_cast<float *>(db + L.raw); env->raw_steps = 1;
+    env->state_copy_out = reinterpret_cast<float *>(db + L.state);      // the rollout kernel leaves the state there itself
     const int rc = run_steps(env, 1, reinterpret_cast<const int32_t *>(db + L.actions), reinterpret_cast<float *>(db + L.obs),
                              reinterpret_cast<float *>(db + L.reward), reinterpret_cast<float *>(db + L.terms),
                              reinterpret_cast<int32_t *>(db + L.covered), reinterpret_cast<uint8_t *>(db + L.done), nullptr, stream,
                              "uavtrack_step_host");
     env->raw_out = raw_was; env->raw_steps = raw_steps_was;
+    env->state_copy_out = nullptr;
     if (rc) return rc;
-    const size_t nst = state_slab_floats(c.n_envs, c.n_uav, c.m_targets, c.dim == 3);
-    hipLaunchKernelGGL(state_snapshot_kernel, dim3((unsigned)((nst + 255) / 256)), dim3(256), 0, st,
-                       reinterpret_cast<const uint32_t *>(env->slab), db + L.state, nst);
-    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
     const float *hf = reinterpret_cast<const float *>(hb);
     const StateBlock sv = state_view(const_cast<float *>(hf + L.state), c.n_envs, c.n_uav, c.m_targets, c.dim == 3);

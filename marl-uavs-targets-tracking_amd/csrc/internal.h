@@ -66,6 +66,7 @@ struct StepParams {
     float *obs, *reward, *terms;
     float2 *tpos;            // optional target trace [T][B][M] (x, y) after each step (uavtrack_set_target_trace)
     float *raw;              // optional raw rewards [T][B][N]: uav.raw_reward of environment.py:219 (uavtrack_set_raw_reward_output)
+    float *state_copy;       // optional second copy of the state slab as it stands behind the launch (uavtrack_step_host: the host block)
     uint32_t *nbrec;         // MAAC-R: neighbour record per agent-step, read by the deferred softmax mix (nbrec_words())
     int32_t *covered;
     uint8_t *done;
@@ -169,6 +170,7 @@ struct uavtrack_env {
     int32_t tpos_steps = 0;
     float *raw_out = nullptr;         // caller's raw-reward buffer (not owned), capacity in steps (uavtrack_set_raw_reward_output)
     int32_t raw_steps = 0;
+    float *state_copy_out = nullptr;  // (during uavtrack_step_host) where the launch leaves a second copy of the state slab
     // uavtrack_step_host: one pinned, device-mapped host block (actions in, every output and a copy of the state out)
     void *host_blk = nullptr;         // host address (hipHostMalloc)
     void *host_blk_dev = nullptr;     // the same block as the device sees it (hipHostGetDevicePointer)

@@ -1435,6 +1435,25 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
             if (EXTRAS) S.episode[b] = epi;
         }
     }
+    // (uavtrack_step_host) the same state once more into the caller-visible copy of the slab: Environment.step's `position`
+    // rows and the uav.x / target.x a host caller reads come out of the launch itself, no snapshot launch behind it
+    if (EXTRAS && p.state_copy) {
+        const StateBlock C2 = state_view(p.state_copy, p.B, N, M, Z3);
+        if (active) {
+            C2.ux[g] = x; C2.uy[g] = y; C2.uh[g] = h; C2.ua[g] = a_prev;
+            if (Z3) C2.uz[g] = z;
+            if (i == 0) { C2.step_count[b] = count; C2.episode[b] = epi; }
+        }
+        for (int q = tid; q < envs_here * M; q += nthreads) {
+            const int te = q / M, k = q - te * M;
+            const size_t gt = (size_t)env0 * M + q;
+            const float *f = reinterpret_cast<const float *>(ttab + te * tstride + (k >> 1) * 2);
+            // (register-resident targets keep their LDS slots current except for the heading, which lives in thd / tth)
+            C2.tx[gt] = f[k & 1]; C2.ty[gt] = f[2 + (k & 1)];
+            C2.th[gt] = (one_target_per_lane && q == tid) ? tth : thd[q];
+            if (Z3) C2.tz[gt] = tzf[te * MP * 2 + k];
+        }
+    }
     if (EXTRAS && p.auto_reset && Z3)      // (target altitudes only ever change at a reset)
         for (int q = tid; q < envs_here * M; q += nthreads) {
             const int te = q / M, k = q - te * M;
@@ -1643,7 +1662,7 @@ hipError_t launch_rollout(uavtrack_env *env, const StepParams &p, hipStream_t st
 {
     int spec = 0;
     const bool allout = p.obs && p.reward && p.terms && p.covered && p.done;
-    const bool extras = p.auto_reset || p.tpos || p.raw;
+    const bool extras = p.auto_reset || p.tpos || p.raw || p.state_copy;
     // MAAC-R: the single-wavefront geometry only pays with the kernel variant written for it (pair-list slots from a pool).
     // Every other launch -- an output not requested, the target trace, the automatic reset -- would run the 4-wave emission
     // path (one pair-list reservation per workgroup-step on ONE counter) on four times the workgroups: measured 15.8

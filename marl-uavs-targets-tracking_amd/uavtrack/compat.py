@@ -187,6 +187,7 @@ class Environment:
             if state is not None:
                 self._env.set_state(**state)
         self._cfg_key = key
+        self._stream = self._env._stream()          # looked up once per handle: every step of this adapter ends synchronised
 
     def _host_state(self):
         """ux uy uh ua tx ty th of the environment as numpy arrays (kept for callers of earlier versions)."""
@@ -246,7 +247,7 @@ class Environment:
             self._pmi_id = id(pmi)
         reference_step_draws(config, self.m_targets)           # target.py:34
         self._act[0, :] = actions
-        v = self._env.step_host(self._act)                     # numpy views of the library's host block
+        v = self._env.step_host(self._act, self._stream)       # numpy views of the library's host block
         covered = int(v["covered"][0])
         self._obs = v["obs"][0].astype(np.float64)
         self._last_reward = v["reward"][0].astype(np.float64)
