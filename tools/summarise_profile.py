@@ -7,6 +7,7 @@ HBM traffic follows MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE an
 collected in separate passes, are in KiB, and on gfx950 FETCH_SIZE counts 64 B per 128-B request for
 wide coalesced reads -- so the read side is reported both raw and doubled."""
 import csv
+import re
 import glob
 import json
 import os
@@ -84,7 +85,7 @@ for k, c in out.items():
             tf = "profiles/traffic.json"
             tr = json.load(open(tf)) if os.path.exists(tf) else {}
             tr[key + ("_scorer" if "pmi_score" in k else "")] = dict(hbm_bytes_per_launch=2 * rb + wb, fetch_bytes_raw=rb, write_bytes=wb,
-                           kernel=k.split("(")[0].split("::")[-1],
+                           kernel=(re.search(r"(\w+_kernel(?:<[^>]*>)?)", k) or [None, k[:60]])[1],
                            source=f"profiles/{tag}_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)")
             json.dump(tr, open(tf, "w"), indent=1, sort_keys=True)
         elif key and "pmi_score" in k:
