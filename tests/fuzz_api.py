@@ -82,7 +82,7 @@ def case(c, rng):
     act = rng.randint(0, na, size=(B, N)).astype(np.int32)
     obs, rew, _ = a.step(torch.from_numpy(act))
     ref = orc.step(act)
-    ok = ref["margin"] > 1e-3
+    ok = ref["margin"] > 2.5e-4
     if ok.any():
         err_o = np.abs(obs.cpu().numpy() - ref["obs"])[ok] / (1.0 + np.abs(ref["obs"][ok]))
         err_r = np.abs(rew.cpu().numpy() - ref["reward"])[ok]
