@@ -16,5 +16,8 @@ timeout -k 10 400 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/b
 rc=$?; [ $rc -ne 0 ] && fail=1; echo "bench rc=$rc" >> $OUT
 timeout -k 10 600 python3 tests/fuzz_api.py 40 > gpurun_out/fuzz.log 2>&1
 rc=$?; [ $rc -ne 0 ] && fail=1; echo "fuzz rc=$rc $(tail -1 gpurun_out/fuzz.log)" >> $OUT
+timeout -k 10 600 python3 tests/soak.py > gpurun_out/soak.log 2>&1
+rc=$?; [ $rc -ne 0 ] && fail=1; echo "soak rc=$rc $(tail -2 gpurun_out/soak.log | head -1)" >> $OUT
+python3 tools/perf_floor.py gpurun_out/bench_k20.json >> $OUT 2>&1
 grep -v amdgpu.ids $OUT
 exit $fail
