@@ -394,7 +394,10 @@ __device__ __forceinline__ void sweep_fast(const StepParams &p, int N, int M, in
         if (Z3) {
             const v2f dzm = (v2f){m2.z, m2.w} - zi2;
             d2m = pk_fma(dzm, dzm, d2m);
-            if (!SYM) {
+            // (the post-move distance serves the duplicate term -- unless that is shared, SYM -- and the neighbour mask of the
+            //  cooperative modes: MAAC-R has both SYM and the mask.  Round 4 shared MAAC-R's duplicate term and left the mask on
+            //  the planar distance in 3-D; found by tests/fuzz_api.py in round 5)
+            if (!SYM || NB) {
                 const float4 n2 = rowNew[jp * 6 + 2];
                 const v2f dzn = (v2f){n2.z, n2.w} - zi2;
                 d2n = pk_fma(dzn, dzn, d2n);

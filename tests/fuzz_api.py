@@ -6,6 +6,7 @@
   3. uavtrack_run_actor(T)        == T x (actor_actions, step), bitwise; probabilities == oracle within 1e-5
   4. MAAC-R teacher-forced step   == fp64 oracle within 1e-5 (random PMI weights, H in {64, 128})
   5. a shard of the batch         == the same environments of the unsharded batch, bitwise
+  6. uavtrack_step_host / raw output == uavtrack_step from the same state, bitwise; raw rewards == oracle within 1e-5
 """
 import os
 import sys
@@ -86,8 +87,34 @@ def case(c, rng):
     if ok.any():
         err_o = np.abs(obs.cpu().numpy() - ref["obs"])[ok] / (1.0 + np.abs(ref["obs"][ok]))
         err_r = np.abs(rew.cpu().numpy() - ref["reward"])[ok]
+        if not (err_o.max() < 1e-5 and err_r.max() < 2e-5):       # diagnostics: which environments, how far from a threshold
+            er_env = np.abs(rew.cpu().numpy() - ref["reward"]).max(1)
+            bad = np.nonzero((er_env > 2e-5) & ok)[0]
+            print(f"{tag}: reward off in envs {bad[:8]}, their fp64 margins {ref['margin'][bad[:8]]}, errors {er_env[bad[:8]]}", flush=True)
         assert err_o.max() < 1e-5 and err_r.max() < 2e-5, f"{tag}: oracle obs {err_o.max():.2e} reward {err_r.max():.2e}"
         assert np.array_equal(a.info["covered"].cpu().numpy()[ok], ref["covered"][ok]), tag
+    # 6. (round 5) the raw-reward output and the host-facing step from the same state as plain steps: raw vs the oracle's
+    #    uav.raw_reward, every other output bit for bit whichever way the step was asked for
+    h1, h2 = make(), make()
+    h1.reset(seed=c + 4); h2.reset(seed=c + 4)
+    rawbuf = torch.empty(1, B, N, device="cuda")
+    h2.set_raw_output(rawbuf)
+    for t in range(min(T, 3)):
+        s2 = host(h2.get_state())
+        orc.set_state(s2["ux"], s2["uy"], s2["uh"], s2["ua"], s2["tx"], s2["ty"], s2["th"], uz=s2.get("uz"), tz=s2.get("tz"))
+        act = rng.randint(0, na, size=(B, N)).astype(np.int32)
+        v = h1.step_host(act)
+        obs, rew, _ = h2.step(torch.from_numpy(act))
+        ref = orc.step(act)
+        assert np.array_equal(v["obs"], obs.cpu().numpy()) and np.array_equal(v["reward"], rew.cpu().numpy()), f"{tag}: step_host t{t}"
+        assert np.array_equal(v["raw"], rawbuf[0].cpu().numpy()) and np.array_equal(v["covered"], h2.info["covered"].cpu().numpy()), tag
+        s3 = host(h2.get_state())
+        for k in ("ux", "uy", "uh", "ua", "tx", "ty", "th") + (("uz", "tz") if dim == 3 else ()):
+            assert np.array_equal(v[k], s3[k]), f"{tag}: step_host state {k}"
+        okr = ref["margin_row"] > 2.5e-4
+        if okr.any():
+            assert np.abs(v["raw"] - ref["raw"])[okr].max() < 1e-5, f"{tag}: raw vs oracle"
+    h1.close(); h2.close()
     # 2. greedy (planar, RAW / MEAN)
     if mode != 2 and dim == 2:
         g1, g2 = make(), make()

@@ -307,3 +307,51 @@ def test_maac_r_calls_capture_into_a_graph_and_growth_is_refused_under_capture(u
     rb = [b.step_many(long_act[k * H:(k + 1) * H]) for k in range(3)]
     assert torch.equal(ra["reward"], torch.cat([r["reward"] for r in rb]))
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("N,M", [(10, 10), (20, 10), (50, 25), (5, 3), (7, 4), (70, 5)])
+@pytest.mark.parametrize("mode", ["raw", "mean", "pmi"])
+def test_3d_ranges_use_the_altitude_in_every_reward_mode(uavtrack, pmi_state_dict, N, M, mode):
+    """3-D with the swarm spread over the WHOLE altitude band (after a reset every UAV flies at z_max / 2 and a few steps of
+    climbing separate them by metres only, so a range test that forgot z would pass): UAVs and targets packed into a 300 m
+    square, altitudes uniform in [0, 600] -- most pairs are within dp in the plane and outside it in space.  Every range test
+    of the step (observation, tracking, coverage, duplicate term, cooperative neighbours) against the oracle, all three
+    reward modes, specialised and general kernels.  (Round 4 shared MAAC-R's duplicate term between the two UAVs of a pair
+    and left its neighbour mask on the planar distance in 3-D: tests/fuzz_api.py found it in round 5.)"""
+    from oracle import OraclePmi
+    B = 40
+    coop = 0.0 if mode == "raw" else 0.3
+    kw = dict(n_envs=B, n_uav=N, m_targets=M, cooperative=coop, dim=3, nc=3, z_max=600.0, x_max=300.0, y_max=300.0)
+    env = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(reward_mode=uavtrack.RewardMode.PMI if mode == "pmi" else None, **kw))
+    orc = OracleEnv(OracleConfig(**kw), n_threads=8)
+    if mode == "pmi":
+        env.set_pmi(pmi_state_dict)
+        orc.pmi = OraclePmi.from_state_dict(pmi_state_dict)
+    env.reset(seed=9)
+    rng = np.random.RandomState(N + M)
+    st = host(env.get_state())
+    st["uz"] = rng.uniform(0.0, 600.0, size=(B, N)).astype(np.float32)
+    st["tz"] = rng.uniform(0.0, 600.0, size=(B, M)).astype(np.float32)
+    env.set_state(**st)
+    planar_only = spatial = 0
+    for t in range(5):
+        cur = host(env.get_state())
+        inject(orc, cur)
+        act = rng.randint(0, 36, size=(B, N)).astype(np.int32)
+        obs, rew, _ = env.step(torch.from_numpy(act))
+        ref = orc.step(act)
+        ok, okr = ref["margin"] > MARGIN, ref["margin_row"] > MARGIN
+        rok = okr if coop == 0 else np.broadcast_to(ok[:, None], okr.shape)
+        np.testing.assert_allclose(obs.cpu().numpy()[okr], ref["obs"][okr], rtol=0, atol=ATOL, err_msg=f"obs t{t}")
+        np.testing.assert_allclose(env.info["terms"].cpu().numpy()[:, okr], ref["terms"][:, okr], rtol=0, atol=ATOL, err_msg=f"terms t{t}")
+        np.testing.assert_allclose(rew.cpu().numpy()[rok], ref["reward"][rok], rtol=0, atol=ATOL, err_msg=f"reward t{t}")
+        np.testing.assert_array_equal(env.info["covered"].cpu().numpy()[ok], ref["covered"][ok], err_msg=f"covered t{t}")
+        nx = host(env.get_state())
+        d2 = (nx["ux"][:, :, None] - nx["ux"][:, None]) ** 2 + (nx["uy"][:, :, None] - nx["uy"][:, None]) ** 2
+        d3 = d2 + (nx["uz"][:, :, None] - nx["uz"][:, None]) ** 2
+        off = ~np.eye(N, dtype=bool)[None]
+        planar_only += int(((d2 <= 200.0 ** 2) & (d3 > 200.0 ** 2) & off).sum())
+        spatial += int(((d3 <= 200.0 ** 2) & off).sum())
+    if N > 1:
+        assert planar_only > 0 and spatial > 0, (planar_only, spatial)      # the scenario separates the planar test from the spatial one
+    env.close()
