@@ -61,8 +61,18 @@ def case(c, rng):
         if mode == 2:
             e.set_pmi({k: torch.from_numpy(v) for k, v in pmi_sd.items()})
         return e
+    def spread(*envs):      # 3-D: a reset leaves every UAV at z_max / 2; half of the cases spread the swarm over the altitude band
+        if dim == 3 and c % 2 == 0:
+            r2 = np.random.RandomState(c)
+            uz = torch.from_numpy(r2.uniform(0.0, 300.0, size=(B, N)).astype(np.float32)).cuda()
+            tz = torch.from_numpy(r2.uniform(0.0, 300.0, size=(B, M)).astype(np.float32)).cuda()
+            for e in envs:
+                st = e.get_state()
+                st["uz"], st["tz"] = uz.clone(), tz.clone()
+                e.set_state(**st)
     a, b = make(), make()
     a.reset(seed=c); b.reset(seed=c)
+    spread(a, b)
     acts = torch.from_numpy(rng.randint(0, na, size=(T, B, N)).astype(np.int32)).cuda()
     # 1. fused == single steps
     fused = a.step_many(acts)
@@ -97,6 +107,7 @@ def case(c, rng):
     #    uav.raw_reward, every other output bit for bit whichever way the step was asked for
     h1, h2 = make(), make()
     h1.reset(seed=c + 4); h2.reset(seed=c + 4)
+    spread(h1, h2)
     rawbuf = torch.empty(1, B, N, device="cuda")
     h2.set_raw_output(rawbuf)
     for t in range(min(T, 3)):

@@ -13,13 +13,18 @@ from oracle import OracleConfig, OracleEnv
 MARGIN = 2.5e-4      # fp64 |d - threshold| below which a result is set aside (tests/test_hip_parity.py)
 
 
-def run(B, N, M, coop, box, steps, seed, dim=2):
+def run(B, N, M, coop, box, steps, seed, dim=2, z_max=300.0, spread_z=False):
     """Per ROW (oracle margin_row: the UAV's own range tests) for the observation row, the terms and the MAAC reward; per
     ENVIRONMENT (margin: every test) for the coverage count and the cooperative rewards -- as in the suite."""
-    kw = dict(n_envs=B, n_uav=N, m_targets=M, cooperative=coop, x_max=box, y_max=box, dim=dim, nc=3 if dim == 3 else 1, z_max=300.0)
+    kw = dict(n_envs=B, n_uav=N, m_targets=M, cooperative=coop, x_max=box, y_max=box, dim=dim, nc=3 if dim == 3 else 1, z_max=z_max)
     env = uavtrack.BatchedUavEnv(uavtrack.EnvConfig(**kw)); env.reset(seed=seed)
     orc = OracleEnv(OracleConfig(**kw), n_threads=16)
     rng = np.random.RandomState(seed)
+    if dim == 3 and spread_z:       # a reset puts every UAV at z_max / 2: spread the swarm and the targets over the whole altitude band
+        st = {k: v for k, v in env.get_state().items()}
+        st["uz"] = torch.from_numpy(rng.uniform(0.0, z_max, size=(B, N)).astype(np.float32)).cuda()
+        st["tz"] = torch.from_numpy(rng.uniform(0.0, z_max, size=(B, M)).astype(np.float32)).cuda()
+        env.set_state(**st)
     worst = dict(obs=0.0, rew=0.0, terms=0.0); bad_cov = 0
     rows_aside = rows = envs_aside = envs = 0
     cen = dict(covered=0, obs=0, reward=0)          # of what is set aside: how much REALLY differs from the oracle
@@ -56,7 +61,7 @@ def run(B, N, M, coop, box, steps, seed, dim=2):
         if okr.any():
             worst["terms"] = max(worst["terms"], float(np.abs(tm - ref["terms"])[:, okr].max()))
         bad_cov += int((cv != ref["covered"])[ok].sum())
-    print(f"B{B} N{N} M{M} coop{coop} box{box} dim{dim} steps{steps}: max|obs|={worst['obs']:.2e} (near origin {worst.get('obs_near_origin', 0.0):.2e}) max|rew|={worst['rew']:.2e} "
+    print(f"B{B} N{N} M{M} coop{coop} box{box} dim{dim}{' z-spread ' + str(z_max) if spread_z else ''} steps{steps}: max|obs|={worst['obs']:.2e} (near origin {worst.get('obs_near_origin', 0.0):.2e}) max|rew|={worst['rew']:.2e} "
           f"max|terms|={worst['terms']:.2e} covered mismatches={bad_cov}; set aside: rows {rows_aside}/{rows}, envs {envs_aside}/{envs}; of those "
           f"really different: covered {cen['covered']}, obs rows {cen['obs']}, reward rows {cen['reward']}", flush=True)
     CENSUS.append((rows_aside, rows, envs_aside, envs, cen["covered"], cen["obs"], cen["reward"]))
@@ -78,7 +83,8 @@ def fuzz(n_cases, seed):
         coop = float(rng.choice([0.0, 0.3, 0.9]))
         box = float(rng.choice([50.0, 300.0, 1000.0, 2000.0, 10000.0]))
         dim = int(rng.choice([2, 2, 3]))
-        run(B, N, M, coop, box, int(rng.choice([3, 8, 20])), 1000 + c, dim=dim)
+        run(B, N, M, coop, box, int(rng.choice([3, 8, 20])), 1000 + c, dim=dim, z_max=float(rng.choice([100.0, 300.0, 1000.0])),
+            spread_z=bool(rng.randint(0, 2)))
 
 
 t0 = time.time()
@@ -92,6 +98,7 @@ if "--quick" not in sys.argv:
 run(2048, 20, 10, 0.3, 300.0, 150, 3)     # tiny box: everything in range, UAVs leave the box, many reflections
 run(1024, 50, 25, 0.3, 2000.0, 60, 4)
 run(1024, 50, 25, 0.0, 2000.0, 40, 5, dim=3)
+run(1024, 20, 10, 0.3, 400.0, 60, 7, dim=3, z_max=600.0, spread_z=True)     # 3-D, altitudes over the whole band: planar and spatial ranges differ
 run(2048, 7, 4, 0.3, 100.0, 300, 6)       # generic kernel, box smaller than a step: origin-weight path, outside-box UAVs
 tot = np.array(CENSUS).sum(0)
 print(f"census: {tot[1]} UAV-steps compared, {tot[0]} set aside on a knife edge ({100.0 * tot[0] / tot[1]:.4f} %); {tot[3]} env-steps, "
