@@ -862,9 +862,9 @@ __global__ void __launch_bounds__(kMaxWorkgroup) rollout_kernel(const StepParams
         // ---- P0 (fused actor rollout only): take_action (actor_critic.py:138-148) on the UAV's own previous
         //      observation, still in registers -- no table, no barrier
         if (ACTOR) {     // whole wavefronts: the two layers run on the matrix cores (actor.h)
-            // (the single-wavefront variant -- the closed loop at the reference shape -- carries a straight layout of the tile
-            //  loop for the reference's hidden width ONLY, 128 = kLoneActorTiles tiles -- launch_rollout sends other widths to the
-            //  4-wave variants; both layouts in one kernel spilled)
+            // (the single-wavefront variant -- the closed loop at the reference shape -- carries the two-tiles-per-trip layout of
+            //  the tile loop, for the reference's hidden width ONLY: 128 = kLoneActorTiles tiles; launch_rollout sends other
+            //  widths to the general variants -- both layouts in one kernel spilled)
             if constexpr (LONE)
                 act = actor_pick<false, actor_tiles(Z3), kLoneActorTiles>(o, p.actor_w, kLoneActorTiles, p.na_total, (uint64_t)(p.env_offset + b),
                                         (uint32_t)count, i, p.greedy_k0, p.greedy_k1, p.actor_mode, nullptr, arng);
