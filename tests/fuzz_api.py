@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Random-shape fuzzing of the fused / policy / MAAC-R entry points (GPU box; run by hand:
-`python tests/fuzz_api.py [cases]`, not collected by pytest).  Per case, with random N, M, B, box, mode:
+`python tests/fuzz_api.py [cases [seed]]`, not collected by pytest).  Per case, with random N, M, B, box, mode:
   1. uavtrack_step_many(T)        == T x uavtrack_step, bitwise (all modes incl. MAAC-R with several chunks)
   2. uavtrack_run_greedy(T)       == T x (greedy_actions, step), bitwise; greedy actions == oracle outside margins
   3. uavtrack_run_actor(T)        == T x (actor_actions, step), bitwise; probabilities == oracle within 1e-5
@@ -184,7 +184,7 @@ def shard_check(c, rng, make, acts, B, off, tag, to_close):
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    rng = np.random.RandomState(11)
+    rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 11)      # (another seed: another set of cases)
     for c in range(n):
         case(c, rng)
     print(f"fuzz_api ok: {n} cases")

@@ -89,7 +89,7 @@ def fuzz(n_cases, seed):
 
 t0 = time.time()
 if "--fuzz" in sys.argv:
-    fuzz(int(sys.argv[sys.argv.index("--fuzz") + 1]), 7)
+    fuzz(int(sys.argv[sys.argv.index("--fuzz") + 1]), int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 7)
     print(f"fuzz ok in {time.time()-t0:.0f} s")
     sys.exit(0)
 if "--quick" not in sys.argv:

@@ -601,3 +601,38 @@ def test_clip_overstep_diagnostics():
     terms, rewards = np.stack(terms), np.stack(rewards)
     got = uavtrack.BatchedUavEnv.clip_saturation(torch.from_numpy(terms), torch.from_numpy(rewards))
     assert got["tracking"] == int((terms[:, 0] >= 1.0).sum()) > 0 and got["duplicate"] == 0 and got["reward"] == 0
+
+
+def test_profile_summary_files_the_scorer_that_moved_the_bytes(tmp_path):
+    """a MAAC-R chunk launches TWO pmi_score* kernels -- the scorer that does the work and the gated stand-by,
+    which returns at once.  tools/summarise_profile.py must file the HBM traffic of the first under the `_scorer` key of
+    profiles/traffic.json (round 4 filed the stand-by's 36 864 B).  Synthetic rocprofv3 counter CSVs, run in a scratch cwd."""
+    import csv
+    import json
+    import shutil
+    import subprocess
+    import sys
+    work = tmp_path / "w"
+    (work / "profiles").mkdir(parents=True)
+    (work / "tools").mkdir()
+    shutil.copy(os.path.join(ROOT, "tools", "summarise_profile.py"), work / "tools" / "summarise_profile.py")
+    t3 = "void uavtrack::(anonymous namespace)::pmi_score_t3_kernel<128>(uavtrack::(anonymous namespace)::PmiParams)"
+    x6 = "void uavtrack::(anonymous namespace)::pmi_score_x6_kernel<128>(uavtrack::(anonymous namespace)::PmiParams)"
+    ro = "void uavtrack::(anonymous namespace)::rollout_kernel<20, 10, 2, false, 0, true, false, true>(uavtrack::StepParams)"
+    cols = ["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value", "VGPR_Count", "SGPR_Count", "LDS_Block_Size",
+            "Scratch_Size", "Workgroup_Size", "Grid_Size"]
+    for counter, vals in (("FETCH_SIZE", {ro: 34000.0, t3: 113000.0, x6: 18.0}), ("WRITE_SIZE", {ro: 1261000.0, t3: 9490.0, x6: 0.0})):
+        d = work / "prof" / f"pmc_{counter.lower()}" / "run"
+        d.mkdir(parents=True)
+        with open(d / "1_counter_collection.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(cols)
+            for k, (name, v) in enumerate(vals.items()):       # the stand-by comes LAST, as in a real trace
+                w.writerow([k + 1, name, counter, v, 128, 96, 0, 0, 256, 65536])
+    r = subprocess.run([sys.executable, "tools/summarise_profile.py", "rXX", "prof", "4096x20x10_T200_pmi128"], cwd=work,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    tr = json.load(open(work / "profiles" / "traffic.json"))
+    sc = tr["4096x20x10_T200_pmi128_scorer"]
+    assert sc["kernel"] == "pmi_score_t3_kernel<128>" and abs(sc["hbm_bytes_per_launch"] - (2 * 113000.0 + 9490.0) * 1024) < 1.0
+    assert tr["4096x20x10_T200_pmi128"]["kernel"].startswith("rollout_kernel<20, 10, 2")
