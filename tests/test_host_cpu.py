@@ -636,3 +636,20 @@ def test_profile_summary_files_the_scorer_that_moved_the_bytes(tmp_path):
     sc = tr["4096x20x10_T200_pmi128_scorer"]
     assert sc["kernel"] == "pmi_score_t3_kernel<128>" and abs(sc["hbm_bytes_per_launch"] - (2 * 113000.0 + 9490.0) * 1024) < 1.0
     assert tr["4096x20x10_T200_pmi128"]["kernel"].startswith("rollout_kernel<20, 10, 2")
+
+
+def test_host_step_struct_mirrors_the_header():
+    """struct uavtrack_host_step (include/uavtrack.h) and its ctypes mirror list the same pointer members in the same order:
+    the adapter reads the library's host block through them."""
+    hdr = open(os.path.join(ROOT, "include", "uavtrack.h")).read()
+    body = re.search(r"typedef struct uavtrack_host_step \{(.*?)\} uavtrack_host_step;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        for m in re.finditer(r"\*\s*(\w+)", decl):
+            names.append(m.group(1))
+    assert names == [k for k, _ in _lib.HostStep._fields_], names
+    assert C.sizeof(_lib.HostStep) == 8 * len(names)
+    # and the entry point's signature: handle, host actions, the struct, the stream
+    res, args = _lib.SIGNATURES["uavtrack_step_host"]
+    assert res is C.c_int and len(args) == 4 and args[2] == C.POINTER(_lib.HostStep)
